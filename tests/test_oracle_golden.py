@@ -1,0 +1,368 @@
+"""Pins the CPU oracle against vectors produced by the reference itself
+(tests/golden/make_golden.py).  Runs on CPU."""
+import numpy as np
+import pytest
+import torch
+
+import goldgen as G
+from conftest import golden, close, close_robust
+from oracle import streamflow_oracle as O
+
+torch.set_num_threads(8)
+
+
+# shapes of the reference modules' state_dicts, restated (SURVEY of src/model/*.py)
+def encoder_shapes(cin, hd, prefix=""):
+    s = {}
+    ch = [cin, hd, hd * 2]
+    for li, idx in enumerate((0, 4)):
+        s[f"{prefix}encoder.{idx}.weight"] = (ch[li + 1], ch[li], 3, 3)
+        for nm in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{prefix}encoder.{idx + 1}.{nm}"] = (ch[li + 1],)
+        s[f"{prefix}encoder.{idx + 1}.num_batches_tracked"] = ()
+    return s
+
+
+def transformer_shapes(din, hd, prefix="", layers=2):
+    s = {f"{prefix}input_proj.weight": (hd, din), f"{prefix}input_proj.bias": (hd,),
+         f"{prefix}pos_encoder.pe": (1, 100, hd)}
+    for l in range(layers):
+        p = f"{prefix}transformer_encoder.layers.{l}."
+        s[p + "self_attn.in_proj_weight"] = (3 * hd, hd)
+        s[p + "self_attn.in_proj_bias"] = (3 * hd,)
+        s[p + "self_attn.out_proj.weight"] = (hd, hd)
+        s[p + "self_attn.out_proj.bias"] = (hd,)
+        s[p + "linear1.weight"] = (4 * hd, hd)
+        s[p + "linear1.bias"] = (4 * hd,)
+        s[p + "linear2.weight"] = (hd, 4 * hd)
+        s[p + "linear2.bias"] = (hd,)
+        for n in ("norm1", "norm2"):
+            s[p + n + ".weight"] = (hd,)
+            s[p + n + ".bias"] = (hd,)
+    return s
+
+
+def lstm_shapes(din, hd, prefix="", layers=2):
+    s = {f"{prefix}input_proj.weight": (hd, din), f"{prefix}input_proj.bias": (hd,)}
+    for l in range(layers):
+        s[f"{prefix}lstm.weight_ih_l{l}"] = (4 * hd, hd)
+        s[f"{prefix}lstm.weight_hh_l{l}"] = (4 * hd, hd)
+        s[f"{prefix}lstm.bias_ih_l{l}"] = (4 * hd,)
+        s[f"{prefix}lstm.bias_hh_l{l}"] = (4 * hd,)
+    return s
+
+
+def decoder_shapes(cin, prefix="", hc=64):
+    return {f"{prefix}conv1.weight": (hc, cin, 3, 3), f"{prefix}conv1.bias": (hc,),
+            f"{prefix}conv2.weight": (hc, hc, 3, 3), f"{prefix}conv2.bias": (hc,),
+            f"{prefix}output_conv.weight": (1, hc, 1, 1), f"{prefix}output_conv.bias": (1,)}
+
+
+def disc_shapes(hc=64, cin=1):
+    s = {"model.0.weight": (hc, cin, 4, 4), "model.0.bias": (hc,)}
+    ch = [hc, hc * 2, hc * 4, hc * 8]
+    for i, li in enumerate((2, 3, 4)):
+        s[f"model.{li}.0.weight"] = (ch[i + 1], ch[i], 4, 4)
+        s[f"model.{li}.0.bias"] = (ch[i + 1],)
+        for nm in ("weight", "bias", "running_mean", "running_var"):
+            s[f"model.{li}.1.{nm}"] = (ch[i + 1],)
+        s[f"model.{li}.1.num_batches_tracked"] = ()
+    s["model.5.weight"] = (1, hc * 8, 4, 4)
+    s["model.5.bias"] = (1,)
+    return s
+
+
+def generator_shapes(cin, hd, temporal):
+    s = encoder_shapes(cin, hd, "cnn_encoder.")
+    feat = hd * 2 * 32 * 32
+    if temporal.upper() == "TRANSFORMER":
+        s.update(transformer_shapes(feat, hd, "temporal_module."))
+    else:
+        s.update(lstm_shapes(feat, hd, "temporal_module."))
+    s["temporal_to_spatial.weight"] = (feat, hd)
+    s["temporal_to_spatial.bias"] = (feat,)
+    s.update(decoder_shapes(hd * 2, "decoder."))
+    return s
+
+
+def gstate(shapes, tag):
+    keep = {k: O.positional_encoding(v[1], v[2]) for k, v in shapes.items() if k.endswith("pos_encoder.pe")}
+    return G.gold_state(shapes, tag, keep=keep)
+
+
+# ------------------------------------------------------------------ tests
+def test_pixel_map_bit_exact():
+    g = golden("pixel_map")
+    for ci, (region, w, h) in enumerate(G.PIXEL_CASES):
+        lon, lat = G.pixel_sweep(region, w, h)
+        px, py = O.lonlat_to_pixel(lon, lat, region, w, h)
+        assert np.array_equal(px, g[f"px{ci}"].astype(np.int64))
+        assert np.array_equal(py, g[f"py{ci}"].astype(np.int64))
+
+
+@pytest.mark.parametrize("size", [64, 128, 200])
+def test_encoder_train(size):
+    g = golden("encoder")
+    sd = gstate(encoder_shapes(4, 16), "enc")
+    x = G.gold_tensor(f"enc/x{size}", (2, 4, size, size))
+    y, upd = O.encoder_forward(x, sd, prefix="", training=True)
+    close(y, g[f"train{size}"])
+    close(upd["encoder.1.running_mean"], g[f"rm1_{size}"])
+    close(upd["encoder.1.running_var"], g[f"rv1_{size}"])
+    close(upd["encoder.5.running_mean"], g[f"rm2_{size}"])
+    close(upd["encoder.5.running_var"], g[f"rv2_{size}"])
+
+
+def test_encoder_eval_and_grads():
+    g = golden("encoder")
+    sd = gstate(encoder_shapes(4, 16), "enc")
+    x = G.gold_tensor("enc/x128", (2, 4, 128, 128))
+    y, _ = O.encoder_forward(x, sd, prefix="", training=False)
+    close(y, g["eval128"])
+    for k in sd:
+        if sd[k].dtype.is_floating_point and "running" not in k:
+            sd[k].requires_grad_(True)
+    x = G.gold_tensor("enc/x200", (2, 4, 200, 200)).requires_grad_(True)
+    y, _ = O.encoder_forward(x, sd, prefix="", training=True)
+    gy = G.gold_tensor("enc/gy200", tuple(y.shape))
+    (y * gy).sum().backward()
+    close(sd["encoder.0.weight"].grad, g["g200_w0"], 2e-5)
+    close(sd["encoder.4.weight"].grad, g["g200_w4"], 2e-5)
+    close(sd["encoder.1.weight"].grad, g["g200_bn1w"], 2e-5)
+    close(sd["encoder.1.bias"].grad, g["g200_bn1b"], 2e-5)
+    close(sd["encoder.5.weight"].grad, g["g200_bn5w"], 2e-5)
+    close(sd["encoder.5.bias"].grad, g["g200_bn5b"], 2e-5)
+    close_robust(x.grad[:, :, ::5, ::5], g["g200_x_sub"], 2e-5)
+
+
+@pytest.mark.parametrize("kind", ["tr", "lstm"])
+def test_temporal(kind):
+    g = golden("temporal")
+    B, T, D_in, Hd = 3, 5, 256, 32
+    shapes = transformer_shapes(D_in, Hd) if kind == "tr" else lstm_shapes(D_in, Hd)
+    sd = gstate(shapes, "tmp_" + kind)
+    fwd = O.transformer_forward if kind == "tr" else O.lstm_forward
+    x0 = G.gold_tensor("tmp/x", (B, T, D_in))
+    with torch.no_grad():
+        close(fwd(x0, sd, prefix=""), g[f"{kind}_y_eval"], 2e-5)
+    for k in sd:
+        if not k.endswith("pe"):
+            sd[k].requires_grad_(True)
+    x = x0.clone().requires_grad_(True)
+    y = fwd(x, sd, prefix="")
+    close(y, g[f"{kind}_y"])
+    (y * G.gold_tensor("tmp/gy", (B, Hd))).sum().backward()
+    close(x.grad, g[f"{kind}_gx"], 2e-5)
+    for k in sd:
+        if not k.endswith("pe"):
+            close(sd[k].grad, g[f"{kind}_g_{k}"], 5e-5)
+
+
+@pytest.mark.parametrize("oh", [64, 100])
+def test_decoder(oh):
+    g = golden("decoder")
+    sd = gstate(decoder_shapes(16), "dec")
+    for k in sd:
+        sd[k].requires_grad_(True)
+    x = G.gold_tensor("dec/x", (2, 16, 32, 32)).requires_grad_(True)
+    y = O.decoder_forward(x, sd, oh, oh, prefix="")
+    close(y, g[f"y{oh}"])
+    (y * G.gold_tensor(f"dec/gy{oh}", tuple(y.shape))).sum().backward()
+    close_robust(x.grad, g[f"gx{oh}"], 2e-5)
+    for k in sd:
+        close(sd[k].grad, g[f"g{oh}_{k}"], 2e-5 if oh == 64 else 1e-3)  # a ReLU flip perturbs every weight grad a little
+
+
+@pytest.mark.parametrize("size", [64, 50])
+def test_discriminator(size):
+    g = golden("discriminator")
+    sd = gstate(disc_shapes(16), "disc")
+    for k in sd:
+        if sd[k].dtype.is_floating_point and "running" not in k:
+            sd[k].requires_grad_(True)
+    x = G.gold_tensor(f"disc/x{size}", (2, 1, size, size)).requires_grad_(True)
+    y, upd = O.discriminator_forward(x, sd)
+    close(y, g[f"y{size}"], 2e-5)
+    (y * G.gold_tensor(f"disc/gy{size}", tuple(y.shape))).sum().backward()
+    close_robust(x.grad, g[f"gx{size}"], 1e-4)
+    for k, v in upd.items():
+        if "running" in k:
+            close(v, g[f"buf{size}_{k}"])
+    for k in sd:
+        if sd[k].requires_grad:
+            if k in ("model.2.0.bias", "model.3.0.bias", "model.4.0.bias"):
+                # a conv bias in front of a train-mode BatchNorm has zero gradient: rounding noise
+                assert float(sd[k].grad.abs().max()) < 1e-4 and float(np.abs(g[f"g{size}_{k}"]).max()) < 1e-4
+            else:
+                close(sd[k].grad, g[f"g{size}_{k}"], 1e-3)
+
+
+def station_cases(H, W):
+    pos = [
+        torch.tensor([[0, 0], [W - 1, H - 1], [5, 7], [6, 7], [5, 7], [W - 1, 0], [1, H - 2]], dtype=torch.int64),
+        torch.zeros((0, 2), dtype=torch.int64),
+        torch.tensor([[10, 3], [11, 4], [W // 2, H // 2]], dtype=torch.int64),
+    ]
+    run = [G.gold_tensor("loss/r0", (7,)), torch.zeros((0,)), G.gold_tensor("loss/r2", (3,))]
+    return pos, run
+
+
+def loss_inputs():
+    B, H, W = 3, 40, 48
+    pred0 = G.gold_tensor("loss/pred", (B, 1, H, W))
+    tgt = G.gold_tensor("loss/tgt", (B, 1, H // 2, W // 2))
+    tgt[:, :, :5, :7] = 0.0
+    tgt_same = G.gold_tensor("loss/tgt_same", (B, 1, H, W))
+    tgt_same[:, :, 10:20, :] = 0.0
+    pos, run = station_cases(H, W)
+    return pred0, tgt, tgt_same, pos, run
+
+
+def test_losses():
+    g = golden("losses")
+    pred0, tgt, tgt_same, pos, run = loss_inputs()
+    for metric in ("MSE", "MAE"):
+        for nm, t in (("up", tgt), ("same", tgt_same)):
+            p = pred0.clone().requires_grad_(True)
+            l = O.image_loss(p, t, metric)
+            l.backward()
+            close(l, g[f"img_{metric}_{nm}"])
+            close(p.grad, g[f"img_{metric}_{nm}_g"])
+        for k in (3, 5):
+            p = pred0.clone().requires_grad_(True)
+            l = O.station_loss(p, pos, run, k, metric)
+            l.backward()
+            close(l, g[f"stn_{metric}_{k}"])
+            close(p.grad, g[f"stn_{metric}_{k}_g"])
+    cfg = {"loss": {"metric": "MSE", "weights": {"image": 1.0, "station": 0.5}},
+           "stations": {"kernel_size": 5, "metric": "MSE"}}
+    p = pred0.clone().requires_grad_(True)
+    ld = O.combined_loss(p, tgt, pos, run, cfg)
+    ld["total"].backward()
+    close(ld["total"], g["comb_total"])
+    close(ld["image"], g["comb_image"])
+    close(ld["station"], g["comb_station"])
+    close(p.grad, g["comb_g"])
+    B = pred0.shape[0]
+    ld = O.combined_loss(pred0, tgt, [torch.zeros((0, 2), dtype=torch.int64)] * B, [torch.zeros(0)] * B, cfg)
+    close(ld["total"], g["comb_nostn_total"])
+    assert float(ld["station"]) == float(g["comb_nostn_station"]) == 0.0
+    lr = G.gold_tensor("loss/logit_real", (B, 1, 5, 6), 2.0)
+    lf = G.gold_tensor("loss/logit_fake", (B, 1, 11, 12), 2.0)
+    a = lf.clone().requires_grad_(True)
+    l = O.bce_with_logits_mean(a, 1.0)
+    l.backward()
+    close(l, g["gan_g"])
+    close(a.grad, g["gan_g_grad"])
+    a = lr.clone().requires_grad_(True)
+    b = lf.clone().requires_grad_(True)
+    l = O.discriminator_loss(a, b)
+    l.backward()
+    close(l, g["gan_d"])
+    close(a.grad, g["gan_d_greal"])
+    close(b.grad, g["gan_d_gfake"])
+    pv = G.gold_array("loss/mp", (200,), 1.0, np.float64) + 3.0
+    tv = pv + G.gold_array("loss/mt", (200,), 0.5, np.float64)
+    m = O.calculate_metrics(pv, tv)
+    np.testing.assert_allclose([m[k] for k in ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE")], g["metrics"],
+                               rtol=1e-12)
+
+
+@pytest.mark.parametrize("temporal", ["LSTM", "Transformer"])
+def test_generator_small(temporal):
+    g = golden("generator")
+    sd = gstate(generator_shapes(3, 16, temporal), "gen_" + temporal)
+    x = G.gold_tensor("gen/x", (2, 5, 3, 64, 64))
+    with torch.no_grad():
+        y, _ = O.generator_forward(x, sd, temporal, training=False)
+        close(y, g[f"{temporal}_eval"], 2e-5)
+        y, _ = O.generator_forward(x, sd, temporal, training=True)
+        close(y, g[f"{temporal}_train"], 2e-5)
+
+
+def test_generator_full_size():
+    g = golden("generator")
+    sd = gstate(generator_shapes(10, 128, "Transformer"), "gen_full")
+    x = G.gold_tensor("gen_full/x", (1, 5, 10, 200, 200))
+    with torch.no_grad():
+        y, _ = O.generator_forward(x, sd, "Transformer", training=False)
+    close(y, g["full_eval"], 2e-5)
+
+
+def train_cfg(temporal, use_gan, accum):
+    return {
+        "data": {"image_size": [64, 64], "window_size": 5, "upscale_factor": 2},
+        "model": {"input_channels": 3, "hidden_dim": 16, "num_layers": 2, "temporal_module": temporal,
+                  "use_gan": use_gan, "gan_weight": 0.1},
+        "train": {"lr": 1e-3},
+        "loss": {"metric": "MSE", "weights": {"image": 1.0, "station": 0.5}},
+        "stations": {"kernel_size": 5, "metric": "MSE"},
+        "system": {"grad_accum_steps": accum},
+    }
+
+
+def make_batches(nb, B, C, size, k_seed="trn"):
+    batches = []
+    for i in range(nb):
+        pos, run = [], []
+        for b in range(B):
+            n = [3, 0, 4, 2][(i + b) % 4]
+            rs = np.random.RandomState(100 * i + b)
+            pos.append(torch.from_numpy(rs.randint(0, size, size=(n, 2)).astype(np.int64)))
+            run.append(torch.from_numpy(rs.standard_normal(n).astype(np.float32)))
+        batches.append({
+            "images": G.gold_tensor(f"{k_seed}/img{i}", (B, 5, C, size, size)),
+            "output_image": G.gold_tensor(f"{k_seed}/out{i}", (B, 1, size, size)),
+            "station_positions": pos, "stations": run,
+        })
+    return batches
+
+
+@pytest.mark.parametrize("temporal,use_gan,accum,tag", [("Transformer", True, 2, "trgan"), ("LSTM", False, 1, "lstm")])
+def test_train_epoch_semantics(temporal, use_gan, accum, tag):
+    """Four batches of Trainer.train_epoch: loss trajectory, the D-schedule quirk and final
+    parameter checksums."""
+    g = golden("train")
+    cfg = train_cfg(temporal, use_gan, accum)
+    gsd = gstate(generator_shapes(3, 16, temporal), "trn_g_" + tag)
+    dsd = gstate(disc_shapes(64), "trn_d_" + tag) if use_gan else None
+    tr = O.TrainerOracle(cfg, gsd, dsd)
+    rows = []
+    for b in make_batches(4, 2, 3, 64):
+        o = tr.step(b["images"], b["output_image"], b["station_positions"], b["stations"])
+        rows.append([o["total"], o["image"], o["station"], o.get("gan_g", np.nan), o.get("gan_d", np.nan)])
+    rows = np.array(rows)
+    ref = g[f"{tag}_losses"]
+    assert np.array_equal(np.isnan(rows), np.isnan(ref))
+    np.testing.assert_allclose(np.nan_to_num(rows), np.nan_to_num(ref), rtol=2e-4)
+    keys = [str(k) for k in g[f"{tag}_gkeys"]]
+    cs = G.checksum(tr.g_sd, keys)
+    got = np.stack([cs[k] for k in keys])
+    np.testing.assert_allclose(got[:, 1], g[f"{tag}_gsum"][:, 1], rtol=2e-4)
+    close(tr.g_sd["decoder.output_conv.weight"], g[f"{tag}_g_dec_out_w"], 1e-3)
+    close(tr.g_sd["cnn_encoder.encoder.1.running_mean"], g[f"{tag}_g_bn1_rm"], 1e-4)
+    if use_gan:
+        keys = [str(k) for k in g[f"{tag}_dkeys"]]
+        cs = G.checksum(tr.d_sd, keys)
+        got = np.stack([cs[k] for k in keys])
+        np.testing.assert_allclose(got[:, 1], g[f"{tag}_dsum"][:, 1], rtol=2e-4)
+        close(tr.d_sd["model.5.bias"], g[f"{tag}_d_m5_b"], 1e-3)
+        close(tr.d_sd["model.2.1.running_var"], g[f"{tag}_d_bn2_rv"], 1e-4)
+
+
+def test_evaluate_path():
+    g = golden("evaluate")
+    cfg = {"data": {"upscale_factor": 2}, "model": {"temporal_module": "LSTM", "num_layers": 2},
+           "stations": {"kernel_size": 3}}
+    sd = gstate(generator_shapes(2, 16, "LSTM"), "eval_g")
+    samples = []
+    for i in range(int(g["n"])):
+        samples.append({"images": torch.from_numpy(g[f"images{i}"]), "output_image": torch.from_numpy(g[f"target{i}"]),
+                        "stations": torch.from_numpy(g[f"stations{i}"]),
+                        "station_positions": torch.from_numpy(g[f"pos{i}"])})
+    res = O.evaluate_samples(samples, sd, cfg)
+    got = np.array([res[k] for k in ("RMSE", "MAE", "SSIM", "PSNR", "Correlation")])
+    np.testing.assert_allclose(got, g["metrics"], rtol=1e-4, atol=1e-5)
+    sm = res["station_metrics"]
+    np.testing.assert_allclose([sm[k] for k in ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE")],
+                               g["station_metrics"], rtol=1e-4, atol=1e-5)
