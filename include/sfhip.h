@@ -1,0 +1,237 @@
+/*
+ * sfhip.h - C ABI of libsfhip.so: hand-written gfx950 (MI355X) kernels for the streamflow
+ * model's training / inference hot path.
+ *
+ * The reference project is pure PyTorch and has no FFI; each entry point below replaces the
+ * stock ATen op(s) that the cited reference lines invoke (paths relative to the reference
+ * checkout).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
+ *   - the library never allocates or frees device memory and keeps no pointer after return;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*), nothing synchronises;
+ *   - return 0 on success, a negative errno-style code otherwise; sf_last_error() returns the
+ *     message of the calling thread's last failure;
+ *   - activations inside the library are NHWC ("channels last") with the channel count padded
+ *     to a multiple of 8; dtype codes: SF_F32 = 0, SF_BF16 = 1.
+ */
+#ifndef SFHIP_H
+#define SFHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_DT_F32 0
+#define SF_DT_BF16 1
+
+#define SF_OUT_NHWC 0 /* out[pixel(j)][i]: conv output, NHWC, placed through sf_conv_geom */
+#define SF_OUT_JI 1   /* out[j*ldo + i] */
+#define SF_OUT_IJ 2   /* out[i*ldo + j] */
+#define SF_OUT_OIHW 3 /* conv weight gradient, f32 OIHW [ldo][cin_real][RS], j = tap*C + c; rows i >= ldo dropped */
+
+int sf_version(void);
+const char* sf_last_error(void);
+
+/* Geometry of a conv-style gather (B operand) and of the NHWC output placement. */
+typedef struct sf_conv_geom {
+    int N, IH, IW, C;       /* gathered tensor [N,IH,IW,C] (C = stored, padded channel count) */
+    int MH, MW;             /* per-image grid of GEMM rows handled by this launch */
+    int sh, sw;             /* gathered coordinate = grid coordinate * stride + tap offset */
+    int OH, OW;             /* output tensor spatial size (SF_OUT_NHWC) */
+    int osh, osw, ooy, oox; /* output coordinate = grid coordinate * ostride + offset */
+    int ntaps;
+    int dy[16], dx[16];     /* tap offsets in gathered coordinates */
+    int tap_rs[16];         /* position of tap t inside the full R*S filter (SF_OUT_OIHW) */
+    int cin_real, RS;       /* real input channels and R*S of the OIHW tensor (SF_OUT_OIHW) */
+} sf_conv_geom;
+
+/*
+ * D[i][j] = sum_r A(i,r) * B(j,r) on the MFMA units (bf16 inputs: v_mfma_f32_32x32x16_bf16;
+ * f32 inputs: v_mfma_f32_32x32x2_f32, i.e. exact f32 FMA chains), f32 accumulation.
+ * One kernel family serves:
+ *   - Conv2d forward and data-gradient as implicit GEMM (A = packed weights [K][taps*C],
+ *     B = conv-gathered NHWC pixels): nn.Conv2d at src/model/cnn_encoder.py:45-51,
+ *     src/model/decoder.py:148-152, src/model/gan.py:26-51;
+ *   - Conv2d weight gradient (A = dOut [pixel][K], B = gathered input [pixel][tap*C], both
+ *     reduction-major);
+ *   - the two 262144-wide nn.Linear layers and their gradients
+ *     (src/model/transformer_module.py:73, src/model/lstm_module.py:36,
+ *     src/model/__init__.py:92-95).
+ */
+typedef struct sf_gemm_desc {
+    int dtype;              /* element type of A and B */
+    int a_kmajor, b_kmajor; /* 0: stored [row][r]; 1: stored [r][row] */
+    int b_gather;           /* 1: B rows (b_kmajor=0) / lines (b_kmajor=1) are gathered pixels */
+    long long I, J, R;
+    long long lda, ldb, ldo;
+    int nsplit;             /* >1: reduction split over blocks, f32 atomic accumulation into out */
+    int out_mode;
+    int out_dtype;
+    int act;                /* 0 none, 1 ReLU, 2 LeakyReLU(0.2); after bias; nsplit == 1 only */
+    int aux_mode;           /* 0 none; 1: out *= (aux > 0); 2: out *= (aux > 0 ? 1 : 0.2) */
+    sf_conv_geom g;
+} sf_gemm_desc;
+
+int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, const float* bias,
+            const void* aux, void* out, void* stream);
+
+/* ---- layout / packing -------------------------------------------------------------- */
+/* NCHW f32 -> NHWC (dtype) with channels zero-padded to Cpad. (images.view at src/model/__init__.py:125) */
+int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad,
+                    void* stream);
+/* NHWC (dtype, Cpad) -> NCHW f32 (first C channels). */
+int sf_nhwc_to_nchw(const void* in, int dtype, float* out, int N, int C, int H, int W, int Cpad,
+                    void* stream);
+/* OIHW f32 weight -> [rows][ntaps][cols_pad] (dtype).  transpose=0: rows=O, cols=I;
+ * transpose=1: rows=I, cols=O (data-gradient operand).  tap t reads filter position tap_rs[t]
+ * (host array of ntaps ints). */
+int sf_pack_conv_weight(const float* w, void* out, int dtype, int O, int I, int RS, int transpose,
+                        int ntaps, const int* tap_rs, int rows_pad, int cols_pad, void* stream);
+/* f32 [n] -> dtype [n] */
+int sf_cast(const float* in, void* out, int dtype, long long n, void* stream);
+
+/* ---- BatchNorm / activation / pooling (src/model/cnn_encoder.py:54-61,69,88-91; src/model/gan.py:32-33) */
+/* Per-channel sum and sum of squares of x[M][C] into ws (2*C doubles, zeroed here). */
+int sf_bn_stats(const void* x, int dtype, long long M, int C, double* ws, void* stream);
+/* training=1: batch statistics from ws (biased var for normalisation; running stats updated
+ * with momentum and the unbiased var).  training=0: running statistics.
+ * Outputs scale = gamma*invstd, shift = beta - mean*scale, and mean / invstd (each [C]). */
+int sf_bn_finalize(const double* ws, long long M, int C, int Creal, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum,
+                   float eps, int training, float* scale, float* shift, float* mean,
+                   float* invstd, void* stream);
+/* y = maxpool2x2(relu(x*scale+shift)); x [N,H,W,C] -> y [N,H/2,W/2,C] */
+int sf_bn_relu_maxpool_fwd(const void* x, int dtype, const float* scale, const float* shift,
+                           void* y, int N, int H, int W, int C, void* stream);
+/* y = adaptive_avg_pool(relu(x*scale+shift)) -> NCHW (out_dtype) [N,Creal,OH,OW]; OH==H: no pooling */
+int sf_bn_relu_avgpool_fwd(const void* x, int dtype, const float* scale, const float* shift,
+                           void* y, int out_dtype, int N, int H, int W, int C, int Creal, int OH,
+                           int OW, void* stream);
+/* y = leaky_relu(x*scale+shift, 0.2), NHWC -> NHWC */
+int sf_bn_lrelu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
+                    long long M, int C, void* stream);
+/*
+ * BatchNorm backward fused with the backward of what follows it.  mode 0: ReLU+maxpool2x2
+ * (dy = gradient wrt the pooled map, NHWC dtype); mode 1: ReLU+adaptive avgpool (dy = NHWC
+ * dtype [N,OH,OW,C]); mode 2: LeakyReLU(0.2) (dy NHWC dtype).
+ * Pass 1 (sf_bn_bwd_reduce) accumulates sum(dz) and sum(dz*xhat) per channel into ws
+ * (2*C doubles, zeroed here); pass 2 (sf_bn_bwd_apply) writes
+ * dx = scale*(dz - mean(dz) - xhat*mean(dz*xhat)) (training) or scale*dz (eval) and
+ * dgamma = sum(dz*xhat), dbeta = sum(dz).
+ */
+int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* dy, int dy_dtype,
+                     const float* scale, const float* shift, const float* mean,
+                     const float* invstd, double* ws, int N, int H, int W, int C, int Creal,
+                     int OH, int OW, void* stream);
+int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* dy, int dy_dtype,
+                    const float* scale, const float* shift, const float* mean,
+                    const float* invstd, const float* gamma, const double* ws, int training,
+                    void* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, int Creal,
+                    int OH, int OW, void* stream);
+/* out[c] = sum_m x[m][c] (bias gradients); out f32 [Creal]; ws: C doubles (zeroed here). */
+int sf_channel_sum(const void* x, int dtype, long long M, int C, int Creal, float* out, double* ws,
+                   void* stream);
+
+/* ---- bilinear resize, align_corners=False (src/model/decoder.py:165-170, src/loss.py:49-54) */
+/* src NHWC f32 [B,h,w,C] -> dst NHWC (dtype) [B,OH,OW,C]; C == Cpad */
+int sf_bilinear_fwd(const void* src, int src_dtype, void* dst, int dtype, int B, int C, int h,
+                    int w, int OH, int OW, int Cpad, void* stream);
+/* ddst NHWC [B,OH,OW,C] -> dsrc NHWC f32 [B,h,w,C]; tmp: B*OH*w*C floats (separable:
+ * reduce along x into tmp, then along y) */
+int sf_bilinear_bwd(const void* ddst, int dtype, float* dsrc, float* tmp, int B, int C, int h,
+                    int w, int OH, int OW, int Cpad, void* stream);
+
+/* ---- small convolutions that do not map onto MFMA tiles ---------------------------- */
+/* First PatchGAN layer: Conv2d(1,K,4,s2,p1)+bias+LeakyReLU (src/model/gan.py:37-41).
+ * x f32 [N,1,H,W]; w f32 [K,1,4,4]; y NHWC dtype [N,OH,OW,K]. */
+int sf_dconv1_fwd(const float* x, const float* w, const float* b, void* y, int dtype, int N,
+                  int H, int W, int K, void* stream);
+/* dz NHWC dtype [N,OH,OW,K] (gradient wrt the pre-activation) -> dx f32 [N,1,H,W] */
+int sf_dconv1_bwd_data(const void* dz, int dtype, const float* w, float* dx, int N, int H, int W,
+                       int K, void* stream);
+/* dw f32 [K,1,4,4], db f32 [K] (both zeroed here, accumulated with atomics) */
+int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, float* dw, float* db, int N,
+                         int H, int W, int K, void* stream);
+/* Single-output-channel conv: Conv2d(C,1,R,s1,pad)+bias (src/model/gan.py:48-51 with R=4,pad=1;
+ * src/model/decoder.py:152 with R=1,pad=0).  x NHWC dtype [N,H,W,C]; w f32 [1,Creal,R,R];
+ * y f32 [N,1,OH,OW]. */
+int sf_conv_k1_fwd(const void* x, int dtype, const float* w, const float* b, float* y, int N,
+                   int H, int W, int C, int Creal, int R, int pad, void* stream);
+/* dx NHWC dtype [N,H,W,C] = sum_taps dy * w, optionally multiplied by (aux>0) (ReLU mask) */
+int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* aux, void* dx, int dtype,
+                        int N, int H, int W, int C, int Creal, int R, int pad, void* stream);
+/* dw f32 [1,Creal,R,R], db f32 [1] (zeroed here) */
+int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, float* dw, float* db, int N,
+                          int H, int W, int C, int Creal, int R, int pad, void* stream);
+
+/* ---- temporal modules ---------------------------------------------------------------- */
+/* One post-LN nn.TransformerEncoderLayer (relu FFN, batch_first) forward / backward for
+ * sequences of T <= 8 steps, d_model <= 128, nhead heads (src/model/transformer_module.py:81-93).
+ * w: the 12 parameter tensors in state_dict order (in_proj_weight, in_proj_bias,
+ * out_proj.weight, out_proj.bias, linear1.weight, linear1.bias, linear2.weight, linear2.bias,
+ * norm1.weight, norm1.bias, norm2.weight, norm2.bias), host array of device pointers.
+ * save: per-sample activations for backward (sf_transformer_save_floats(T,D,F) floats each).
+ * p_drop / seed: dropout probability (training) and Philox-free counter hash seed. */
+size_t sf_transformer_save_floats(int T, int D, int F);
+int sf_transformer_layer_fwd(const float* x, float* y, const float* const* w, float* save, int B,
+                             int T, int D, int F, int nhead, float p_drop,
+                             unsigned long long seed, void* stream);
+/* x: the layer's forward input; dw: 12 f32 gradient tensors (accumulated with atomics; caller zeroes) */
+int sf_transformer_layer_bwd(const float* x, const float* dy, float* dx, const float* const* w, float* const* dw,
+                             const float* save, int B, int T, int D, int F, int nhead,
+                             float p_drop, unsigned long long seed, void* stream);
+/* x[B,T,D] + pe[T,D] (fwd) ; mean over T -> [B,D] (src/model/transformer_module.py:112,118) */
+int sf_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, void* stream);
+int sf_mean_t_fwd(const float* x, float* y, int B, int T, int D, void* stream);
+int sf_mean_t_bwd(const float* dy, float* dx, int B, int T, int D, void* stream);
+/* nn.LSTM(H,H,L,batch_first), gate order i,f,g,o, zero initial state, returns h_n[-1]
+ * (src/model/lstm_module.py:40-47,66-75).  w: per layer W_ih, W_hh, b_ih, b_hh (4*L pointers).
+ * save: sf_lstm_save_floats(T,H,L) floats per sample. */
+size_t sf_lstm_save_floats(int T, int H, int L);
+int sf_lstm_fwd(const float* x, float* y, const float* const* w, float* save, int B, int T, int H,
+                int L, float p_drop, unsigned long long seed, void* stream);
+int sf_lstm_bwd(const float* x, const float* dy, float* dx, const float* const* w, float* const* dw,
+                const float* save, int B, int T, int H, int L, float p_drop,
+                unsigned long long seed, void* stream);
+
+/* ---- losses ---------------------------------------------------------------------------- */
+/* StreamflowDataset._lonlat_to_pixel (src/dataset.py:352-373): float64 arithmetic in the
+ * reference's order, round-half-to-even, clamp.  lon/lat device f64 [n]; out int32 [n] each. */
+int sf_lonlat_to_pixel(const double* lon, const double* lat, int n, double lon_min, double lon_max,
+                       double lat_min, double lat_max, int W, int H, int* px, int* py,
+                       void* stream);
+/*
+ * Fused ImageLoss + StationLoss forward AND backward (src/loss.py:47-70, 116-160, 227-230).
+ * pred f32 [B,1,H,W]; target f32 [B,1,TH,TW] (bilinearly resized to HxW on the fly when the
+ * sizes differ); stations packed: pos int32 [S][2] (x=column, y=row), runoff f32 [S],
+ * sample offsets int32 [B+1].  metric 0 = MSE, 1 = MAE (image_metric / station_metric).
+ * losses[0..2] = total, image, station.  dpred f32 [B,1,H,W] = d total / d pred.
+ * ws: 4 doubles (zeroed here).
+ */
+int sf_image_station_loss(const float* pred, const float* target, const int* pos,
+                          const float* runoff, const int* offsets, int S, int B, int H, int W,
+                          int TH, int TW, int image_metric, float nonzero_weight,
+                          float zero_threshold, int ksize, int station_metric, float image_weight,
+                          float station_weight, float* losses, float* dpred, double* ws,
+                          void* stream);
+/* mean BCE-with-logits (src/model/gan.py:82,102-108) against `labels` (f32 [n]) or, when
+ * labels is NULL, the constant `label`:
+ * loss[0] = mean(max(x,0) - x*y + log1p(exp(-|x|))); dx (nullable) = (sigmoid(x) - y)/n. ws: 1 double. */
+int sf_bce_logits(const float* x, long long n, float label, const float* labels, float* loss,
+                  float* dx, double* ws, void* stream);
+/* out[c] = sum_m x[m][c] for a short, very wide f32 matrix (bias gradient of the 262144-wide Linear) */
+int sf_colsum_f32(const float* x, long long M, long long C, float* out, void* stream);
+
+/* ---- optimiser --------------------------------------------------------------------------- */
+/* torch.optim.Adam step (src/train.py:80-91; eps 1e-8, no weight decay), one fused pass over
+ * a flat parameter range.  bias corrections are passed in (1-beta^t). */
+int sf_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+            float beta2, float eps, float bc1, float bc2, float grad_scale, void* stream);
+/* flag[0] |= 1 if any element of x is NaN/Inf (src/train.py:193,198,221) */
+int sf_nan_inf_flag(const float* x, long long n, int* flag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

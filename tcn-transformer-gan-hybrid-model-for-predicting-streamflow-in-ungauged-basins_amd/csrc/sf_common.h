@@ -1,0 +1,105 @@
+// Shared device / host helpers for the streamflow HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SF_OK 0
+#define SF_EINVAL (-22)
+#define SF_ELAUNCH (-5)
+#define SF_ENOSYS (-38)
+
+#define SF_F32 0
+#define SF_BF16 1
+
+#define SF_ACT_NONE 0
+#define SF_ACT_RELU 1
+#define SF_ACT_LRELU 2
+
+void sf_set_error(const char* fmt, ...);
+
+#define SF_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            sf_set_error(__VA_ARGS__);                          \
+            return SF_EINVAL;                                   \
+        }                                                       \
+    } while (0)
+
+#define SF_LAUNCH_CHECK(name)                                                          \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            sf_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));       \
+            return SF_ELAUNCH;                                                         \
+        }                                                                              \
+    } while (0)
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    static constexpr int CODE = SF_F32;
+};
+template <> struct ElemTraits<bf16> {
+    static constexpr int EPC = 8;
+    static constexpr int CODE = SF_BF16;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// 4 consecutive elements of T, loaded / stored as one vector access
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ float get(int i) const { return (&v.x)[i]; }
+    __device__ __forceinline__ void set(int i, float f) { (&v.x)[i] = f; }
+};
+template <> struct Vec4<bf16> {
+    bf16x4 v;
+    __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x4*>(p); }
+    __device__ __forceinline__ void store(bf16* p) const { *reinterpret_cast<bf16x4*>(p) = v; }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16)f; }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sum over a 256-thread block; result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* sm /* >= 4 floats */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ double block_sum_256_d(double v, double* sm) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,447 @@
+// Convolutions whose shapes do not fill MFMA tiles: the PatchGAN's first layer (one input
+// channel) and single-output-channel convs (PatchGAN head, decoder 1x1).  They are HBM / L2
+// bound; lanes run over 16-byte channel chunks and reduce with wave shuffles.
+#include "sf_common.h"
+#include "../../include/sfhip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+template <typename T> __device__ __forceinline__ void load_chunk(const T* p, float* f);
+template <> __device__ __forceinline__ void load_chunk<float>(const float* p, float* f) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ __forceinline__ void load_chunk<bf16>(const bf16* p, float* f) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ void store_chunk(T* p, const float* f);
+template <> __device__ __forceinline__ void store_chunk<float>(float* p, const float* f) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+}
+template <> __device__ __forceinline__ void store_chunk<bf16>(bf16* p, const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
+
+inline int grid_for(long long items, int cap = 8192) {
+    long long b = (items + NT - 1) / NT;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// Sum `vals[nv]` over the row phases of each channel group (thread = phase*G + cg) and add the
+// totals atomically: out_index(cg, v) gives the destination of value v of group cg (or -1).
+template <int NV, typename F>
+__device__ __forceinline__ void reduce_phases_atomic(const float* vals, int G, int rpp, float* sm /*[8][NT]*/,
+                                                     float* out, F out_index) {
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    for (int v0 = 0; v0 < NV; v0 += 8) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (v0 + v < NV) sm[v * NT + threadIdx.x] = vals[v0 + v];
+        __syncthreads();
+        if (phase == 0) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                if (v0 + v < NV) {
+                    float t = 0.f;
+                    for (int ph = 0; ph < rpp; ++ph) t += sm[v * NT + ph * G + cg];
+                    const long long idx = out_index(cg, v0 + v);
+                    if (idx >= 0) atomicAdd(out + idx, t);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ first PatchGAN layer
+template <typename T>
+__global__ void dconv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ b, T* __restrict__ y, int N, int H, int W, int K,
+                                  int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    extern __shared__ float sw[];  // [16][K] + [K]
+    for (int i = threadIdx.x; i < 16 * K; i += NT) {
+        const int t = i / K, k = i % K;
+        sw[i] = w[k * 16 + t];
+    }
+    for (int i = threadIdx.x; i < K; i += NT) sw[16 * K + i] = b[i];
+    __syncthreads();
+    const int G = K / EPC;
+    const long long total = (long long)N * OH * OW * G;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int cg = (int)(o % G);
+        long long r = o / G;
+        const int ow = (int)(r % OW); r /= OW;
+        const int oh = (int)(r % OH);
+        const long long n = r / OH;
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = sw[16 * K + cg * EPC + e];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int iy = oh * 2 - 1 + (t >> 2), ix = ow * 2 - 1 + (t & 3);
+            float xv = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) xv = x[(n * H + iy) * W + ix];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += xv * sw[t * K + cg * EPC + e];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.2f * acc[e];
+        store_chunk<T>(y + o * EPC, acc);
+    }
+}
+
+template <typename T>
+__global__ void dconv1_bwd_data_kernel(const T* __restrict__ dz, const float* __restrict__ w,
+                                       float* __restrict__ dx, int N, int H, int W, int K, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    extern __shared__ float sw[];  // [16][K]
+    for (int i = threadIdx.x; i < 16 * K; i += NT) {
+        const int t = i / K, k = i % K;
+        sw[i] = w[k * 16 + t];
+    }
+    __syncthreads();
+    const int G = K / EPC;
+    const long long total = (long long)N * H * W;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int ix = (int)(o % W);
+        const long long r = o / W;
+        const int iy = (int)(r % H);
+        const long long n = r / H;
+        float acc = 0.f;
+        // taps with (iy + 1 - r) even and the quotient inside the output map
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int ty = iy + 1 - rr;
+            if (ty < 0 || (ty & 1)) continue;
+            const int oh = ty >> 1;
+            if (oh >= OH) continue;
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                const int tx = ix + 1 - ss;
+                if (tx < 0 || (tx & 1)) continue;
+                const int ow = tx >> 1;
+                if (ow >= OW) continue;
+                const T* src = dz + ((n * OH + oh) * OW + ow) * K;
+                const float* wt = sw + (rr * 4 + ss) * K;
+                for (int cg = 0; cg < G; ++cg) {
+                    float f[EPC];
+                    load_chunk<T>(src + cg * EPC, f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc += f[e] * wt[cg * EPC + e];
+                }
+            }
+        }
+        dx[o] = acc;
+    }
+}
+
+template <typename T>
+__global__ void dconv1_bwd_weight_kernel(const float* __restrict__ x, const T* __restrict__ dz,
+                                         float* __restrict__ dw, float* __restrict__ db, int N, int H, int W,
+                                         int K, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int NV = 17 * EPC;
+    __shared__ float sm[8 * NT];
+    const int G = K / EPC, rpp = NT / G;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    const long long M = (long long)N * OH * OW;
+    if (phase < rpp) {
+        for (long long m = (long long)blockIdx.x * rpp + phase; m < M; m += (long long)gridDim.x * rpp) {
+            const int ow = (int)(m % OW);
+            const long long r = m / OW;
+            const int oh = (int)(r % OH);
+            const long long n = r / OH;
+            float f[EPC];
+            load_chunk<T>(dz + m * K + cg * EPC, f);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int iy = oh * 2 - 1 + (t >> 2), ix = ow * 2 - 1 + (t & 3);
+                float xv = 0.f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) xv = x[(n * H + iy) * W + ix];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[t * EPC + e] += xv * f[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[16 * EPC + e] += f[e];
+        }
+    }
+    // value v = t*EPC + e -> dw[(cg*EPC+e)*16 + t]; t == 16 -> db
+    float* outs[1] = {dw};
+    (void)outs;
+    reduce_phases_atomic<NV>(acc, G, rpp, sm, dw, [&](int g, int v) -> long long {
+        const int t = v / EPC, e = v % EPC;
+        if (t < 16) return (long long)(g * EPC + e) * 16 + t;
+        return -1;
+    });
+    reduce_phases_atomic<EPC>(acc + 16 * EPC, G, rpp, sm, db, [&](int g, int v) -> long long {
+        return (long long)g * EPC + v;
+    });
+}
+
+// ------------------------------------------------------------------ single-output-channel conv
+// a group of LPP lanes handles one output pixel; lanes run over channel chunks.
+template <typename T>
+__global__ void conv_k1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                   float* __restrict__ y, int N, int H, int W, int C, int Creal, int R, int pad,
+                                   int OH, int OW, int LPP) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = C / EPC, RS = R * R;
+    const int lane_in = threadIdx.x % LPP;
+    const long long gid = (blockIdx.x * (long long)NT + threadIdx.x) / LPP;
+    const long long ngroups = ((long long)gridDim.x * NT) / LPP;
+    const long long total = (long long)N * OH * OW;
+    const long long rounds = (total + ngroups - 1) / ngroups;
+    for (long long it = 0; it < rounds; ++it) {
+        const long long o = gid + it * ngroups;
+        const bool ok = o < total;
+        float acc = 0.f;
+        if (ok) {
+            const int ow = (int)(o % OW);
+            const long long r = o / OW;
+            const int oh = (int)(r % OH);
+            const long long n = r / OH;
+            for (int t = 0; t < RS; ++t) {
+                const int iy = oh - pad + t / R, ix = ow - pad + t % R;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const T* src = x + ((n * H + iy) * W + ix) * C;
+                for (int cg = lane_in; cg < G; cg += LPP) {
+                    float f[EPC];
+                    load_chunk<T>(src + cg * EPC, f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const int c = cg * EPC + e;
+                        if (c < Creal) acc += f[e] * w[c * RS + t];
+                    }
+                }
+            }
+        }
+        for (int off = LPP >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (ok && lane_in == 0) y[o] = acc + b[0];
+    }
+}
+
+template <typename T>
+__global__ void conv_k1_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                        const T* __restrict__ aux, T* __restrict__ dx, int N, int H, int W, int C,
+                                        int Creal, int R, int pad, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = C / EPC, RS = R * R;
+    const long long total = (long long)N * H * W * G;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int cg = (int)(o % G);
+        long long r = o / G;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const long long n = r / H;
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (int t = 0; t < RS; ++t) {
+            const int oh = iy + pad - t / R, ow = ix + pad - t % R;
+            if (oh < 0 || oh >= OH || ow < 0 || ow >= OW) continue;
+            const float g = dy[(n * OH + oh) * OW + ow];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = cg * EPC + e;
+                if (c < Creal) acc[e] += g * w[c * RS + t];
+            }
+        }
+        if (aux) {
+            float a[EPC];
+            load_chunk<T>(aux + o * EPC, a);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = a[e] > 0.f ? acc[e] : 0.f;
+        }
+        store_chunk<T>(dx + o * EPC, acc);
+    }
+}
+
+template <typename T, int RS>
+__global__ void conv_k1_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ dy,
+                                          float* __restrict__ dw, float* __restrict__ db, int N, int H, int W, int C,
+                                          int Creal, int R, int pad, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int NV = RS * EPC;
+    __shared__ float sm[8 * NT];
+    const int G = C / EPC, rpp = NT / G;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    const long long M = (long long)N * OH * OW;
+    if (phase < rpp) {
+        for (long long m = (long long)blockIdx.x * rpp + phase; m < M; m += (long long)gridDim.x * rpp) {
+            const int ow = (int)(m % OW);
+            const long long r = m / OW;
+            const int oh = (int)(r % OH);
+            const long long n = r / OH;
+            const float g = dy[m];
+            if (cg == 0) bsum += g;
+#pragma unroll
+            for (int t = 0; t < RS; ++t) {
+                const int iy = oh - pad + t / R, ix = ow - pad + t % R;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                float f[EPC];
+                load_chunk<T>(x + ((n * H + iy) * W + ix) * C + cg * EPC, f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[t * EPC + e] += g * f[e];
+            }
+        }
+    }
+    reduce_phases_atomic<NV>(acc, G, rpp, sm, dw, [&](int g, int v) -> long long {
+        const int t = v / EPC, e = v % EPC;
+        const int c = g * EPC + e;
+        return c < Creal ? (long long)c * RS + t : -1;
+    });
+    reduce_phases_atomic<1>(&bsum, G, rpp, sm, db, [&](int g, int v) -> long long { return g == 0 ? 0 : -1; });
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                       \
+    if ((dtype) == SF_BF16) { using T = bf16; CALL; }                 \
+    else if ((dtype) == SF_F32) { using T = float; CALL; }            \
+    else { sf_set_error("bad dtype %d", (int)(dtype)); return SF_EINVAL; }
+
+static int dconv1_dims(const char* who, int dtype, int N, int H, int W, int K, int* OH, int* OW) {
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    if (N <= 0 || H < 2 || W < 2 || K <= 0 || K % epc != 0 || K / epc > NT || NT % (K / epc) != 0) {
+        sf_set_error("%s: unsupported shape N=%d H=%d W=%d K=%d", who, N, H, W, K);
+        return SF_EINVAL;
+    }
+    *OH = (H + 2 - 4) / 2 + 1;
+    *OW = (W + 2 - 4) / 2 + 1;
+    return SF_OK;
+}
+
+extern "C" int sf_dconv1_fwd(const float* x, const float* w, const float* b, void* y, int dtype, int N, int H, int W,
+                             int K, void* stream) {
+    SF_REQUIRE(x && w && b && y, "sf_dconv1_fwd: null argument");
+    int OH, OW;
+    if (int rc = dconv1_dims("sf_dconv1_fwd", dtype, N, H, W, K, &OH, &OW)) return rc;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const long long total = (long long)N * OH * OW * (K / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_fwd_kernel<T>, dim3(grid_for(total)), dim3(NT), sizeof(float) * 17 * K,
+                                         (hipStream_t)stream, x, w, b, (T*)y, N, H, W, K, OH, OW));
+    SF_LAUNCH_CHECK("sf_dconv1_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_dconv1_bwd_data(const void* dz, int dtype, const float* w, float* dx, int N, int H, int W, int K,
+                                  void* stream) {
+    SF_REQUIRE(dz && w && dx, "sf_dconv1_bwd_data: null argument");
+    int OH, OW;
+    if (int rc = dconv1_dims("sf_dconv1_bwd_data", dtype, N, H, W, K, &OH, &OW)) return rc;
+    const long long total = (long long)N * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_bwd_data_kernel<T>, dim3(grid_for(total)), dim3(NT),
+                                         sizeof(float) * 16 * K, (hipStream_t)stream, (const T*)dz, w, dx, N, H, W, K,
+                                         OH, OW));
+    SF_LAUNCH_CHECK("sf_dconv1_bwd_data");
+    return SF_OK;
+}
+
+extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, float* dw, float* db, int N, int H,
+                                    int W, int K, void* stream) {
+    SF_REQUIRE(x && dz && dw && db, "sf_dconv1_bwd_weight: null argument");
+    int OH, OW;
+    if (int rc = dconv1_dims("sf_dconv1_bwd_weight", dtype, N, H, W, K, &OH, &OW)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * 16 * K, s) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float) * K, s) != hipSuccess) {
+        sf_set_error("sf_dconv1_bwd_weight: memset failed");
+        return SF_ELAUNCH;
+    }
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const int rpp = NT / (K / epc);
+    const long long M = (long long)N * OH * OW;
+    int grid = (int)((M + rpp - 1) / rpp); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_bwd_weight_kernel<T>, dim3(grid), dim3(NT), 0, s, x, (const T*)dz, dw,
+                                         db, N, H, W, K, OH, OW));
+    SF_LAUNCH_CHECK("sf_dconv1_bwd_weight");
+    return SF_OK;
+}
+
+static int k1_dims(const char* who, int dtype, int N, int H, int W, int C, int Creal, int R, int pad, int* OH,
+                   int* OW) {
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    if (N <= 0 || C <= 0 || C % epc != 0 || Creal > C || Creal <= 0 || (R != 1 && R != 4) || pad < 0 ||
+        C / epc > NT || NT % (C / epc) != 0) {
+        sf_set_error("%s: unsupported shape N=%d H=%d W=%d C=%d R=%d", who, N, H, W, C, R);
+        return SF_EINVAL;
+    }
+    *OH = H + 2 * pad - R + 1;
+    *OW = W + 2 * pad - R + 1;
+    if (*OH <= 0 || *OW <= 0) {
+        sf_set_error("%s: empty output", who);
+        return SF_EINVAL;
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_conv_k1_fwd(const void* x, int dtype, const float* w, const float* b, float* y, int N, int H, int W,
+                              int C, int Creal, int R, int pad, void* stream) {
+    SF_REQUIRE(x && w && b && y, "sf_conv_k1_fwd: null argument");
+    int OH, OW;
+    if (int rc = k1_dims("sf_conv_k1_fwd", dtype, N, H, W, C, Creal, R, pad, &OH, &OW)) return rc;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    int lpp = 1;
+    while (lpp < C / epc && lpp < 64) lpp <<= 1;
+    const long long total = (long long)N * OH * OW;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(conv_k1_fwd_kernel<T>, dim3(grid_for(total * lpp)), dim3(NT), 0,
+                                         (hipStream_t)stream, (const T*)x, w, b, y, N, H, W, C, Creal, R, pad, OH, OW,
+                                         lpp));
+    SF_LAUNCH_CHECK("sf_conv_k1_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* aux, void* dx, int dtype, int N, int H,
+                                   int W, int C, int Creal, int R, int pad, void* stream) {
+    SF_REQUIRE(dy && w && dx, "sf_conv_k1_bwd_data: null argument");
+    int OH, OW;
+    if (int rc = k1_dims("sf_conv_k1_bwd_data", dtype, N, H, W, C, Creal, R, pad, &OH, &OW)) return rc;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const long long total = (long long)N * H * W * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(conv_k1_bwd_data_kernel<T>, dim3(grid_for(total)), dim3(NT), 0,
+                                         (hipStream_t)stream, dy, w, (const T*)aux, (T*)dx, N, H, W, C, Creal, R, pad,
+                                         OH, OW));
+    SF_LAUNCH_CHECK("sf_conv_k1_bwd_data");
+    return SF_OK;
+}
+
+extern "C" int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, float* dw, float* db, int N, int H,
+                                     int W, int C, int Creal, int R, int pad, void* stream) {
+    SF_REQUIRE(x && dy && dw && db, "sf_conv_k1_bwd_weight: null argument");
+    int OH, OW;
+    if (int rc = k1_dims("sf_conv_k1_bwd_weight", dtype, N, H, W, C, Creal, R, pad, &OH, &OW)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * Creal * R * R, s) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float), s) != hipSuccess) {
+        sf_set_error("sf_conv_k1_bwd_weight: memset failed");
+        return SF_ELAUNCH;
+    }
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const int rpp = NT / (C / epc);
+    const long long M = (long long)N * OH * OW;
+    int grid = (int)((M + rpp - 1) / rpp); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+    if (R == 1) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((conv_k1_bwd_weight_kernel<T, 1>), dim3(grid), dim3(NT), 0, s, (const T*)x,
+                                             dy, dw, db, N, H, W, C, Creal, R, pad, OH, OW));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((conv_k1_bwd_weight_kernel<T, 16>), dim3(grid), dim3(NT), 0, s,
+                                             (const T*)x, dy, dw, db, N, H, W, C, Creal, R, pad, OH, OW));
+    }
+    SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
+    return SF_OK;
+}

@@ -1,0 +1,481 @@
+// MFMA GEMM / implicit-GEMM convolution family (see sf_gemm in include/sfhip.h).
+//
+// D[i][j] = sum_r A(i,r) * B(j,r).  Block tile TI x 128 (i x j), 4 waves as 2 x 2, each wave
+// (TI/2) x 64 built from 32x32 MFMA tiles.  Operand tiles go global -> registers -> LDS
+// (double-buffered, one barrier per reduction step); a tile is either "row-major"
+// [row][r] (fragments = contiguous r) or "reduction-major" [r][row] (fragments read through
+// ds_read_b64_tr_b16 for bf16, plain b32 reads for f32).  The B operand can be a conv gather
+// of NHWC pixels (zero padding by predication).
+#include "sf_common.h"
+#include "../../include/sfhip.h"
+
+namespace {
+
+constexpr int TJ = 128;
+constexpr int NTHREADS = 256;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static constexpr int KSTEP = 16;
+    static constexpr int BK = 32;
+    static constexpr int PAD_RM = 8;   // row-major tile row padding (elements)
+    static constexpr int PAD_KM = 32;  // reduction-major tile line padding
+    using Frag = bf16x8;
+    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    // row-major tile: lane (r=lane&31, h=lane>>5) holds elements r0..r0+7, r0 = ks*16 + 8h
+    static __device__ __forceinline__ Frag load_rm(const bf16* t, int ld, int row0, int ks, int lane) {
+        return *reinterpret_cast<const bf16x8*>(&t[(row0 + (lane & 31)) * ld + ks * 16 + 8 * (lane >> 5)]);
+    }
+    // reduction-major tile [line][col]: the lane needs 8 consecutive lines at one column ->
+    // two transposed 4x16 block reads.
+    static __device__ __forceinline__ Frag load_km(const bf16* t, int ld, int col0, int ks, int lane) {
+        const int line = ks * 16 + 8 * (lane >> 5) + ((lane & 15) >> 2);
+        const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        typedef bf16x4 __attribute__((address_space(3))) * lds_p;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(&t[line * ld + col]));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(&t[(line + 4) * ld + col]));
+        Frag f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KSTEP = 2;
+    static constexpr int BK = 16;
+    static constexpr int PAD_RM = 1;
+    static constexpr int PAD_KM = 4;
+    using Frag = float;
+    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ Frag load_rm(const float* t, int ld, int row0, int ks, int lane) {
+        return t[(row0 + (lane & 31)) * ld + ks * 2 + (lane >> 5)];
+    }
+    static __device__ __forceinline__ Frag load_km(const float* t, int ld, int col0, int ks, int lane) {
+        return t[(ks * 2 + (lane >> 5)) * ld + col0 + (lane & 31)];
+    }
+};
+
+struct KParams {
+    const void* A;
+    const void* B;
+    void* out;
+    const float* bias;
+    const void* aux;
+    long long I, J, R, lda, ldb, ldo;
+    int niters, iters_per_split, nsplit, ni_tiles, nj_tiles;
+    int b_gather, out_mode, out_dtype, act, aux_mode, atomic;
+    sf_conv_geom g;
+};
+
+template <typename T, bool ALIGNED> __device__ __forceinline__ void lds_store16(T* dst, uint4 v) {
+    if constexpr (ALIGNED) {
+        *reinterpret_cast<uint4*>(dst) = v;
+    } else {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, rem = nwg & 7, x = bid & 7, idx = bid >> 3;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
+}
+
+template <typename T, bool A_KM, bool B_KM, int TI>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
+    using M = Mma<T>;
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = M::BK;
+    constexpr int LDA = A_KM ? (TI + M::PAD_KM) : (BK + M::PAD_RM);
+    constexpr int LDB = B_KM ? (TJ + M::PAD_KM) : (BK + M::PAD_RM);
+    constexpr int A_ELEMS = A_KM ? BK * LDA : TI * LDA;
+    constexpr int B_ELEMS = B_KM ? BK * LDB : TJ * LDB;
+    constexpr int A_CHUNKS = TI * BK / EPC;   // 16-byte chunks per A tile
+    constexpr int B_CHUNKS = TJ * BK / EPC;
+    constexpr int NA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;
+    constexpr int NB = B_CHUNKS / NTHREADS;
+    constexpr int A_CPL = A_KM ? TI / EPC : BK / EPC;  // chunks per stored line
+    constexpr int B_CPL = B_KM ? TJ / EPC : BK / EPC;
+    constexpr bool A_AL = A_KM || (sizeof(T) == 2);
+    constexpr bool B_AL = B_KM || (sizeof(T) == 2);
+    constexpr int MT = TI / 64;  // 32-row MFMA tiles per wave along i
+    constexpr int NT = 2;        // along j
+    static_assert(A_CHUNKS % NTHREADS == 0 || A_CHUNKS < NTHREADS, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) T smem[2 * (A_ELEMS + B_ELEMS)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+
+    // block -> (i tile, j tile, split)
+    const int nwg = gridDim.x;
+    int lin = xcd_remap(blockIdx.x, nwg);
+    const int it_i = lin % p.ni_tiles;
+    lin /= p.ni_tiles;
+    const int it_j = lin % p.nj_tiles;
+    const int split = lin / p.nj_tiles;
+    const long long i0 = (long long)it_i * TI, j0 = (long long)it_j * TJ;
+    const int iter_begin = split * p.iters_per_split;
+    int iter_end = iter_begin + p.iters_per_split;
+    if (iter_end > p.niters) iter_end = p.niters;
+
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B);
+    const sf_conv_geom& g = p.g;
+
+    // ---- per-thread chunk bookkeeping -------------------------------------------------
+    // A chunks
+    int a_line[NA], a_cc[NA];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) {
+        const int ch = tid + c * NTHREADS;
+        a_line[c] = ch / A_CPL;
+        a_cc[c] = ch % A_CPL;
+    }
+    // B chunks
+    int b_line[NB], b_cc[NB];
+    // gather state: row-major gather -> fixed pixel per chunk; reduction-major gather -> fixed
+    // (tap, channel) per chunk and a pixel that advances by BK every iteration.
+    int gp_n[NB], gp_a[NB], gp_b[NB], gp_t[NB], gp_c[NB];
+    bool gp_ok[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const int ch = tid + c * NTHREADS;
+        b_line[c] = ch / B_CPL;
+        b_cc[c] = ch % B_CPL;
+        gp_n[c] = gp_a[c] = gp_b[c] = gp_t[c] = gp_c[c] = 0;
+        gp_ok[c] = true;
+        if (p.b_gather) {
+            if constexpr (!B_KM) {
+                const long long j = j0 + b_line[c];
+                gp_ok[c] = j < p.J;
+                const long long jj = gp_ok[c] ? j : 0;
+                const int per = g.MH * g.MW;
+                gp_n[c] = (int)(jj / per);
+                const int rem = (int)(jj - (long long)gp_n[c] * per);
+                gp_a[c] = rem / g.MW;
+                gp_b[c] = rem - gp_a[c] * g.MW;
+            } else {
+                const long long jcol = j0 + (long long)b_cc[c] * EPC;
+                gp_ok[c] = jcol < p.J;
+                const int jj = gp_ok[c] ? (int)jcol : 0;
+                gp_t[c] = jj / g.C;
+                gp_c[c] = jj - gp_t[c] * g.C;
+                const long long m = (long long)iter_begin * BK + b_line[c];
+                const int per = g.MH * g.MW;
+                gp_n[c] = (int)(m / per);
+                const int rem = (int)(m - (long long)gp_n[c] * per);
+                gp_a[c] = rem / g.MW;
+                gp_b[c] = rem - gp_a[c] * g.MW;
+            }
+        }
+    }
+    const bool c_div_bk = (g.C % BK) == 0;
+
+    uint4 ra[NA], rb[NB];
+
+    auto load_tiles = [&](int it) {
+        const long long r0 = (long long)it * BK;
+        // ---- A
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (NA * NTHREADS == A_CHUNKS || tid + c * NTHREADS < A_CHUNKS) {
+                if constexpr (!A_KM) {
+                    const long long i = i0 + a_line[c];
+                    const long long r = r0 + (long long)a_cc[c] * EPC;
+                    if (i < p.I && r < p.R) v = *reinterpret_cast<const uint4*>(Ag + i * p.lda + r);
+                } else {
+                    const long long r = r0 + a_line[c];
+                    const long long i = i0 + (long long)a_cc[c] * EPC;
+                    if (r < p.R && i < p.I) v = *reinterpret_cast<const uint4*>(Ag + r * p.lda + i);
+                }
+            }
+            ra[c] = v;
+        }
+        // ---- B
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if constexpr (!B_KM) {
+                const long long r = r0 + (long long)b_cc[c] * EPC;
+                if (!p.b_gather) {
+                    const long long j = j0 + b_line[c];
+                    if (j < p.J && r < p.R) v = *reinterpret_cast<const uint4*>(Bg + j * p.ldb + r);
+                } else if (gp_ok[c] && r < p.R) {
+                    int t, cc;
+                    if (c_div_bk) {
+                        t = (int)(r0 / g.C);
+                        cc = (int)(r - (long long)t * g.C);
+                    } else {
+                        t = (int)(r / g.C);
+                        cc = (int)(r - (long long)t * g.C);
+                    }
+                    const int iy = gp_a[c] * g.sh + g.dy[t];
+                    const int ix = gp_b[c] * g.sw + g.dx[t];
+                    if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
+                        const long long pix = ((long long)gp_n[c] * g.IH + iy) * g.IW + ix;
+                        v = *reinterpret_cast<const uint4*>(Bg + pix * g.C + cc);
+                    }
+                }
+            } else {
+                const long long r = r0 + b_line[c];
+                if (!p.b_gather) {
+                    const long long j = j0 + (long long)b_cc[c] * EPC;
+                    if (r < p.R && j < p.J) v = *reinterpret_cast<const uint4*>(Bg + r * p.ldb + j);
+                } else if (gp_ok[c] && r < p.R) {
+                    const int iy = gp_a[c] * g.sh + g.dy[gp_t[c]];
+                    const int ix = gp_b[c] * g.sw + g.dx[gp_t[c]];
+                    if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
+                        const long long pix = ((long long)gp_n[c] * g.IH + iy) * g.IW + ix;
+                        v = *reinterpret_cast<const uint4*>(Bg + pix * g.C + gp_c[c]);
+                    }
+                }
+            }
+            rb[c] = v;
+        }
+        if constexpr (B_KM) {
+            if (p.b_gather) {
+                // advance every chunk's pixel by BK grid positions
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    gp_b[c] += BK;
+                    while (gp_b[c] >= g.MW) { gp_b[c] -= g.MW; gp_a[c] += 1; }
+                    while (gp_a[c] >= g.MH) { gp_a[c] -= g.MH; gp_n[c] += 1; }
+                }
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        T* sa = smem + buf * (A_ELEMS + B_ELEMS);
+        T* sb = sa + A_ELEMS;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            if (NA * NTHREADS == A_CHUNKS || tid + c * NTHREADS < A_CHUNKS)
+                lds_store16<T, A_AL>(sa + a_line[c] * LDA + a_cc[c] * EPC, ra[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) lds_store16<T, B_AL>(sb + b_line[c] * LDB + b_cc[c] * EPC, rb[c]);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    if (iter_begin < iter_end) {
+        load_tiles(iter_begin);
+        for (int it = iter_begin; it < iter_end; ++it) {
+            const int buf = (it - iter_begin) & 1;
+            store_tiles(buf);
+            __syncthreads();
+            if (it + 1 < iter_end) load_tiles(it + 1);
+            const T* sa = smem + buf * (A_ELEMS + B_ELEMS);
+            const T* sb = sa + A_ELEMS;
+#pragma unroll
+            for (int ks = 0; ks < BK / M::KSTEP; ++ks) {
+                typename M::Frag fa[MT], fb[NT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const int row0 = wi * (TI / 2) + a * 32;
+                    fa[a] = A_KM ? M::load_km(sa, LDA, row0, ks, lane) : M::load_rm(sa, LDA, row0, ks, lane);
+                }
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int row0 = wj * 64 + b * 32;
+                    fb[b] = B_KM ? M::load_km(sb, LDB, row0, ks, lane) : M::load_rm(sb, LDB, row0, ks, lane);
+                }
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) acc[a][b] = M::mma(fa[a], fb[b], acc[a][b]);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds column j = lane&31, rows i = 8g + 4h + e ------------------
+    const int h = lane >> 5;
+    const bool atomic = p.atomic != 0;
+    const bool add_bias = p.bias != nullptr && split == 0;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const long long j = j0 + wj * 64 + b * 32 + (lane & 31);
+        if (j >= p.J) continue;
+        long long jloc = j;  // output "pixel" index
+        int tap = 0, cch = 0;
+        if (p.out_mode == SF_OUT_NHWC) {
+            const int per = g.MH * g.MW;
+            const int n = (int)(j / per);
+            const int rem = (int)(j - (long long)n * per);
+            const int a = rem / g.MW, bb = rem - a * g.MW;
+            jloc = ((long long)n * g.OH + (a * g.osh + g.ooy)) * g.OW + (bb * g.osw + g.oox);
+        } else if (p.out_mode == SF_OUT_OIHW) {
+            tap = (int)(j / g.C);
+            cch = (int)(j - (long long)tap * g.C);
+            if (cch >= g.cin_real) continue;
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const long long i = i0 + wi * (TI / 2) + a * 32 + 8 * gq + 4 * h;
+                if (i >= p.I) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * gq + e];
+                if (p.out_mode == SF_OUT_NHWC || p.out_mode == SF_OUT_JI) {
+                    const long long off = jloc * p.ldo + i;
+                    if (add_bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += p.bias[i + e];
+                    }
+                    if (atomic) {
+                        float* o = reinterpret_cast<float*>(p.out) + off;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(o + e, v[e]);
+                    } else {
+                        if (p.act == SF_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        } else if (p.act == SF_ACT_LRELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                        }
+                        if (p.aux_mode) {
+                            Vec4<T> ax;
+                            ax.load(reinterpret_cast<const T*>(p.aux) + off);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool pos = ax.get(e) > 0.f;
+                                v[e] = pos ? v[e] : (p.aux_mode == 1 ? 0.f : 0.2f * v[e]);
+                            }
+                        }
+                        if (p.out_dtype == SF_F32) {
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + off) =
+                                make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            Vec4<bf16> o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o.set(e, v[e]);
+                            o.store(reinterpret_cast<bf16*>(p.out) + off);
+                        }
+                    }
+                } else if (p.out_mode == SF_OUT_IJ) {
+                    float* o = reinterpret_cast<float*>(p.out);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const long long off = (i + e) * p.ldo + j;
+                        if (atomic) atomicAdd(o + off, v[e]); else o[off] = v[e];
+                    }
+                } else {  // SF_OUT_OIHW (always accumulated atomically)
+                    float* o = reinterpret_cast<float*>(p.out);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (i + e >= p.ldo) continue;  // ldo = real output-channel count of the OIHW tensor
+                        const long long off = ((i + e) * g.cin_real + cch) * g.RS + g.tap_rs[tap];
+                        atomicAdd(o + off, v[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, bool A_KM, bool B_KM>
+int launch(const KParams& p, hipStream_t s) {
+    const int TIsel = p.I <= 64 ? 64 : 128;
+    KParams q = p;
+    q.ni_tiles = ceil_div(p.I, TIsel);
+    q.nj_tiles = ceil_div(p.J, TJ);
+    const long long nblk = (long long)q.ni_tiles * q.nj_tiles * q.nsplit;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) {
+        sf_set_error("sf_gemm: bad grid (%lld blocks)", nblk);
+        return SF_EINVAL;
+    }
+    dim3 grid((unsigned)nblk), block(NTHREADS);
+    if (TIsel == 64)
+        hipLaunchKernelGGL((gemm_kernel<T, A_KM, B_KM, 64>), grid, block, 0, s, q);
+    else
+        hipLaunchKernelGGL((gemm_kernel<T, A_KM, B_KM, 128>), grid, block, 0, s, q);
+    SF_LAUNCH_CHECK("sf_gemm");
+    return SF_OK;
+}
+
+template <typename T> int dispatch(const sf_gemm_desc* d, const KParams& p, hipStream_t s) {
+    if (!d->a_kmajor && !d->b_kmajor) return launch<T, false, false>(p, s);
+    if (d->a_kmajor && d->b_kmajor) return launch<T, true, true>(p, s);
+    if (d->a_kmajor && !d->b_kmajor) return launch<T, true, false>(p, s);
+    sf_set_error("sf_gemm: a row-major / b reduction-major is not built");
+    return SF_ENOSYS;
+}
+
+}  // namespace
+
+extern "C" int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, const float* bias,
+                       const void* aux, void* out, void* stream) {
+    SF_REQUIRE(d && A && B && out, "sf_gemm: null argument");
+    SF_REQUIRE(d->dtype == SF_F32 || d->dtype == SF_BF16, "sf_gemm: bad dtype %d", d->dtype);
+    const int epc = d->dtype == SF_BF16 ? 8 : 4;
+    const int bk = d->dtype == SF_BF16 ? 32 : 16;
+    SF_REQUIRE(d->I > 0 && d->J > 0 && d->R > 0, "sf_gemm: empty problem");
+    SF_REQUIRE(d->I % 4 == 0, "sf_gemm: I=%lld must be a multiple of 4", d->I);
+    SF_REQUIRE(d->nsplit >= 1, "sf_gemm: nsplit < 1");
+    SF_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sf_gemm: operands must be 16-byte aligned");
+    if (d->a_kmajor) SF_REQUIRE(d->I % epc == 0 && d->lda % epc == 0, "sf_gemm: reduction-major A needs I, lda %% %d == 0", epc);
+    else SF_REQUIRE(d->R % epc == 0 && d->lda % epc == 0, "sf_gemm: row-major A needs R, lda %% %d == 0", epc);
+    if (d->b_gather) {
+        const sf_conv_geom& g = d->g;
+        SF_REQUIRE(g.ntaps >= 1 && g.ntaps <= 16, "sf_gemm: ntaps out of range");
+        SF_REQUIRE(g.C % epc == 0, "sf_gemm: gathered channel count %d must be a multiple of %d", g.C, epc);
+        SF_REQUIRE(g.N > 0 && g.MH > 0 && g.MW > 0 && g.IH > 0 && g.IW > 0, "sf_gemm: bad geometry");
+        const long long rows = (long long)g.N * g.MH * g.MW;
+        if (!d->b_kmajor) {
+            SF_REQUIRE(d->J == rows, "sf_gemm: J=%lld != N*MH*MW=%lld", d->J, rows);
+            SF_REQUIRE(d->R == (long long)g.ntaps * g.C, "sf_gemm: R != ntaps*C");
+        } else {
+            SF_REQUIRE(d->R == rows, "sf_gemm: R=%lld != N*MH*MW=%lld", d->R, rows);
+            SF_REQUIRE(d->J == (long long)g.ntaps * g.C, "sf_gemm: J != ntaps*C");
+        }
+    } else if (d->b_kmajor) {
+        SF_REQUIRE(d->J % epc == 0 && d->ldb % epc == 0, "sf_gemm: reduction-major B needs J, ldb %% %d == 0", epc);
+    } else {
+        SF_REQUIRE(d->R % epc == 0 && d->ldb % epc == 0, "sf_gemm: row-major B needs R, ldb %% %d == 0", epc);
+    }
+    if (d->out_mode == SF_OUT_NHWC) {
+        const sf_conv_geom& g = d->g;
+        SF_REQUIRE(d->b_gather && !d->b_kmajor, "sf_gemm: NHWC output needs a row-major gathered B");
+        SF_REQUIRE((g.MH - 1) * g.osh + g.ooy < g.OH && (g.MW - 1) * g.osw + g.oox < g.OW && g.ooy >= 0 && g.oox >= 0,
+                   "sf_gemm: output placement outside the output tensor");
+        SF_REQUIRE(d->ldo >= d->I && d->ldo % 4 == 0, "sf_gemm: ldo");
+    }
+    if (d->out_mode == SF_OUT_OIHW) SF_REQUIRE(d->b_gather && d->b_kmajor && d->g.RS >= 1 && d->g.cin_real >= 1 && d->ldo >= 1 && d->ldo <= d->I, "sf_gemm: OIHW output needs a reduction-major gathered B and ldo = real output channels");
+    if (d->out_mode == SF_OUT_JI) SF_REQUIRE(d->ldo % 4 == 0, "sf_gemm: ldo %% 4");
+    if (d->nsplit > 1) SF_REQUIRE(d->out_dtype == SF_F32 && d->act == 0 && d->aux_mode == 0, "sf_gemm: split reduction needs plain f32 output");
+    if (d->out_mode == SF_OUT_IJ || d->out_mode == SF_OUT_OIHW) SF_REQUIRE(d->out_dtype == SF_F32 && d->act == 0 && d->aux_mode == 0 && bias == nullptr, "sf_gemm: IJ/OIHW output is plain f32");
+    if (d->aux_mode) SF_REQUIRE(aux != nullptr, "sf_gemm: aux_mode without aux");
+
+    KParams p;
+    p.A = A; p.B = B; p.out = out; p.bias = bias; p.aux = aux;
+    p.I = d->I; p.J = d->J; p.R = d->R; p.lda = d->lda; p.ldb = d->ldb; p.ldo = d->ldo;
+    p.niters = ceil_div(d->R, bk);
+    p.nsplit = d->nsplit > p.niters ? p.niters : d->nsplit;
+    p.iters_per_split = ceil_div(p.niters, p.nsplit);
+    p.nsplit = ceil_div(p.niters, p.iters_per_split);
+    p.ni_tiles = p.nj_tiles = 0;
+    p.b_gather = d->b_gather; p.out_mode = d->out_mode; p.out_dtype = d->out_dtype;
+    p.act = d->act; p.aux_mode = d->aux_mode; p.g = d->g;
+    // a requested split keeps its accumulate-into-out semantics even when it degenerates to one slice
+    p.atomic = (d->nsplit > 1 || d->out_mode == SF_OUT_OIHW) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (d->dtype == SF_BF16) rc = dispatch<bf16>(d, p, s); else rc = dispatch<float>(d, p, s);
+    return rc;
+}

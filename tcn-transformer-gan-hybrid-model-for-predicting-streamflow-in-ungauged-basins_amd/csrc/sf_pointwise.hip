@@ -1,0 +1,841 @@
+// HBM-bound passes: layout changes, weight packing, BatchNorm statistics / apply / backward
+// fused with ReLU + pooling or LeakyReLU, bias-gradient sums, bilinear resize.
+// Every kernel moves 16-byte channel chunks of NHWC tensors per lane.
+#include "sf_common.h"
+#include "../../include/sfhip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+template <typename T> __device__ __forceinline__ void load_chunk(const T* p, float* f);
+template <> __device__ __forceinline__ void load_chunk<float>(const float* p, float* f) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ __forceinline__ void load_chunk<bf16>(const bf16* p, float* f) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ void store_chunk(T* p, const float* f);
+template <> __device__ __forceinline__ void store_chunk<float>(float* p, const float* f) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+}
+template <> __device__ __forceinline__ void store_chunk<bf16>(bf16* p, const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
+
+inline int grid_for(long long items, int cap = 4096) {
+    long long b = (items + NT - 1) / NT;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------ layout
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, long long npix_total,
+                                    int C, int HW, int Cpad) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    for (long long pix = blockIdx.x * (long long)NT + threadIdx.x; pix < npix_total;
+         pix += (long long)gridDim.x * NT) {
+        const long long n = pix / HW;
+        const int hw = (int)(pix - n * HW);
+        const float* src = in + n * C * (long long)HW + hw;
+        for (int c0 = 0; c0 < Cpad; c0 += EPC) {
+            float f[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = (c0 + e < C) ? src[(long long)(c0 + e) * HW] : 0.f;
+            store_chunk<T>(out + pix * Cpad + c0, f);
+        }
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, long long total, int C,
+                                    int HW, int Cpad) {
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int hw = (int)(o % HW);
+        const long long nc = o / HW;
+        const int c = (int)(nc % C);
+        const long long n = nc / C;
+        out[o] = to_f32(in[(n * HW + hw) * Cpad + c]);
+    }
+}
+
+struct PackArgs {
+    int O, I, RS, transpose, ntaps, rows_pad, cols_pad;
+    int tap_rs[16];
+};
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, PackArgs a) {
+    const long long total = (long long)a.rows_pad * a.ntaps * a.cols_pad;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int col = (int)(o % a.cols_pad);
+        const long long rt = o / a.cols_pad;
+        const int t = (int)(rt % a.ntaps);
+        const int row = (int)(rt / a.ntaps);
+        const int oc = a.transpose ? col : row;
+        const int ic = a.transpose ? row : col;
+        float v = 0.f;
+        if (oc < a.O && ic < a.I) v = w[((long long)oc * a.I + ic) * a.RS + a.tap_rs[t]];
+        out[o] = from_f32<T>(v);
+    }
+}
+
+template <typename T> __global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, long long n) {
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT)
+        out[i] = from_f32<T>(in[i]);
+}
+
+// ------------------------------------------------------------------------------ BN statistics
+// thread -> (channel group, row phase); rows strided over the grid; double accumulation.
+template <typename T, bool SQ>
+__global__ void colsum_kernel(const T* __restrict__ x, long long M, int C, double* __restrict__ ws) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = C / EPC;  // <= NT (checked by the host)
+    const int rpp = NT / G;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    const bool active = phase < rpp;
+    __shared__ double sm[NT * 2];
+    double s[EPC], q[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.0;
+    if (active) {
+        for (long long r = (long long)blockIdx.x * rpp + phase; r < M; r += (long long)gridDim.x * rpp) {
+            float f[EPC];
+            load_chunk<T>(x + r * C + cg * EPC, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s[e] += (double)f[e];
+                if (SQ) q[e] += (double)f[e] * (double)f[e];
+            }
+        }
+    }
+    // combine the row phases of one channel group through LDS
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        __syncthreads();
+        sm[threadIdx.x] = s[e];
+        sm[NT + threadIdx.x] = q[e];
+        __syncthreads();
+        if (active && phase == 0) {
+            double ts = 0.0, tq = 0.0;
+            for (int ph = 0; ph < rpp; ++ph) {
+                ts += sm[ph * G + cg];
+                tq += sm[NT + ph * G + cg];
+            }
+            atomicAdd(&ws[cg * EPC + e], ts);
+            if (SQ) atomicAdd(&ws[C + cg * EPC + e], tq);
+        }
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, long long M, int C, int Creal,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
+                                   int training, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_o, float* __restrict__ invstd_o) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        if (c >= Creal) {
+            scale[c] = 0.f; shift[c] = 0.f; mean_o[c] = 0.f; invstd_o[c] = 0.f;
+            continue;
+        }
+        float mean, var;
+        if (training) {
+            const double m = ws[c] / (double)M;
+            double v = ws[C + c] / (double)M - m * m;
+            if (v < 0.0) v = 0.0;
+            mean = (float)m;
+            var = (float)v;
+            const double unb = M > 1 ? v * ((double)M / (double)(M - 1)) : v;
+            rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+            rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+        } else {
+            mean = rm[c];
+            var = rv[c];
+        }
+        const float inv = 1.0f / sqrtf(var + eps);
+        const float sc = gamma[c] * inv;
+        scale[c] = sc;
+        shift[c] = beta[c] - mean * sc;
+        mean_o[c] = mean;
+        invstd_o[c] = inv;
+    }
+}
+
+// ------------------------------------------------------------------------------ BN + ReLU + maxpool forward
+template <typename T>
+__global__ void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, T* __restrict__ y, int N, int H,
+                                           int W, int C) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = C / EPC, PH = H / 2, PW = W / 2;
+    const long long total = (long long)N * PH * PW * G;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int cg = (int)(o % G);
+        long long r = o / G;
+        const int pw = (int)(r % PW); r /= PW;
+        const int ph = (int)(r % PH);
+        const long long n = r / PH;
+        float sc[EPC], sf[EPC], m[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { sc[e] = scale[cg * EPC + e]; sf[e] = shift[cg * EPC + e]; m[e] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = ph * 2 + (k >> 1), w = pw * 2 + (k & 1);
+            float f[EPC];
+            load_chunk<T>(x + ((n * H + h) * W + w) * C + cg * EPC, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float v = f[e] * sc[e] + sf[e];
+                m[e] = v > m[e] ? v : m[e];  // max with 0 == ReLU then max
+            }
+        }
+        store_chunk<T>(y + ((n * PH + ph) * PW + pw) * C + cg * EPC, m);
+    }
+}
+
+// ------------------------------------------------------------------------------ BN + ReLU + adaptive avgpool -> NCHW
+__device__ __forceinline__ int bin_start(int i, int in, int out) { return (i * in) / out; }
+__device__ __forceinline__ int bin_end(int i, int in, int out) { return ((i + 1) * in + out - 1) / out; }
+
+template <typename T, typename TO>
+__global__ void bn_relu_avgpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, TO* __restrict__ y, int N, int H,
+                                           int W, int C, int Creal, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int CS = 128;  // channel slab staged through LDS
+    extern __shared__ float tile[];  // [CS][OW+1]
+    const int n = blockIdx.x / OH, oh = blockIdx.x % OH;
+    const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
+    const int ldt = OW + 1;
+    for (int c0 = 0; c0 < Creal; c0 += CS) {
+        const int cs = (Creal - c0) < CS ? (Creal - c0) : CS;
+        const int gs = (cs + EPC - 1) / EPC;
+        __syncthreads();
+        for (int it = threadIdx.x; it < gs * OW; it += NT) {
+            const int cg = it % gs, ow = it / gs;
+            const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+            float sc[EPC], sf[EPC], acc[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                sc[e] = scale[c0 + cg * EPC + e]; sf[e] = shift[c0 + cg * EPC + e]; acc[e] = 0.f;
+            }
+            for (int h = h0; h < h1; ++h)
+                for (int w = w0; w < w1; ++w) {
+                    float f[EPC];
+                    load_chunk<T>(x + (((long long)n * H + h) * W + w) * C + c0 + cg * EPC, f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float v = f[e] * sc[e] + sf[e];
+                        acc[e] += v > 0.f ? v : 0.f;
+                    }
+                }
+            const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) tile[(cg * EPC + e) * ldt + ow] = acc[e] * inv;
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < cs * OW; it += NT) {
+            const int ow = it % OW, c = it / OW;
+            y[(((long long)n * Creal + c0 + c) * OH + oh) * OW + ow] = from_f32<TO>(tile[c * ldt + ow]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void bn_lrelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, T* __restrict__ y, long long M, int C) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = C / EPC;
+    const long long total = M * G;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int cg = (int)(o % G);
+        float f[EPC];
+        load_chunk<T>(x + o * EPC, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float v = f[e] * scale[cg * EPC + e] + shift[cg * EPC + e];
+            f[e] = v > 0.f ? v : 0.2f * v;
+        }
+        store_chunk<T>(y + o * EPC, f);
+    }
+}
+
+// ------------------------------------------------------------------------------ BN backward
+struct BnBwd {
+    const void* x; const void* dy;
+    const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
+    int N, H, W, C, Creal, OH, OW, training;
+};
+
+// dz (gradient wrt the BN output) for one channel chunk at pre-BN pixel (n,h,w).
+// MODE 1: ReLU + adaptive average pool (dy NHWC [N,OH,OW,C]); MODE 2: LeakyReLU (dy NHWC [N,H,W,C]).
+template <typename T, int MODE>
+__device__ __forceinline__ void dz_at(const BnBwd& a, long long n, int h, int w, int cg, const float* xf,
+                                      float* dz) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const T* dy = reinterpret_cast<const T*>(a.dy);
+    if (MODE == 2) {
+        float g[EPC];
+        load_chunk<T>(dy + ((n * a.H + h) * a.W + w) * a.C + cg * EPC, g);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float y = xf[e] * a.scale[cg * EPC + e] + a.shift[cg * EPC + e];
+            dz[e] = y > 0.f ? g[e] : 0.2f * g[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dz[e] = 0.f;
+        int ilo = (h * a.OH) / a.H - 1; if (ilo < 0) ilo = 0;
+        int ihi = ((h + 1) * a.OH + a.H - 1) / a.H; if (ihi > a.OH - 1) ihi = a.OH - 1;
+        int jlo = (w * a.OW) / a.W - 1; if (jlo < 0) jlo = 0;
+        int jhi = ((w + 1) * a.OW + a.W - 1) / a.W; if (jhi > a.OW - 1) jhi = a.OW - 1;
+        for (int i = ilo; i <= ihi; ++i) {
+            const int hs = bin_start(i, a.H, a.OH), he = bin_end(i, a.H, a.OH);
+            if (h < hs || h >= he) continue;
+            for (int j = jlo; j <= jhi; ++j) {
+                const int ws_ = bin_start(j, a.W, a.OW), we = bin_end(j, a.W, a.OW);
+                if (w < ws_ || w >= we) continue;
+                float g[EPC];
+                load_chunk<T>(dy + ((n * a.OH + i) * a.OW + j) * a.C + cg * EPC, g);
+                const float inv = 1.0f / (float)((he - hs) * (we - ws_));
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) dz[e] += g[e] * inv;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float y = xf[e] * a.scale[cg * EPC + e] + a.shift[cg * EPC + e];
+            dz[e] = y > 0.f ? dz[e] : 0.f;
+        }
+    }
+}
+
+// MODE 0 (ReLU + maxpool 2x2): work item = one pooling window; dzk[k][e] for its 4 pixels.
+template <typename T>
+__device__ __forceinline__ void dz_window(const BnBwd& a, long long n, int ph, int pw, int cg,
+                                          float xf[4][ElemTraits<T>::EPC], bool valid[4],
+                                          float dz[4][ElemTraits<T>::EPC]) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* dy = reinterpret_cast<const T*>(a.dy);
+    const int PH = a.H / 2, PW = a.W / 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = ph * 2 + (k >> 1), w = pw * 2 + (k & 1);
+        valid[k] = h < a.H && w < a.W;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { xf[k][e] = 0.f; dz[k][e] = 0.f; }
+        if (valid[k]) load_chunk<T>(x + ((n * a.H + h) * a.W + w) * a.C + cg * EPC, xf[k]);
+    }
+    if (ph < PH && pw < PW) {
+        float g[EPC];
+        load_chunk<T>(dy + ((n * PH + ph) * PW + pw) * a.C + cg * EPC, g);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float sc = a.scale[cg * EPC + e], sf = a.shift[cg * EPC + e];
+            float best = xf[0][e] * sc + sf;
+            int arg = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float v = xf[k][e] * sc + sf;
+                if (v > best) { best = v; arg = k; }
+            }
+            // ReLU precedes the pool: a window whose maximum is <= 0 passes no gradient
+            if (best > 0.f) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dz[k][e] = (k == arg) ? g[e] : 0.f;
+            }
+        }
+    }
+}
+
+template <typename T, int MODE>
+__global__ void bn_bwd_reduce_kernel(BnBwd a, double* __restrict__ ws) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = a.C / EPC;
+    const int rpp = NT / G > 0 ? NT / G : 1;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    const bool active = G <= NT && phase < rpp;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    double s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.0;
+    float mu[EPC], is[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { mu[e] = a.mean[cg * EPC + e]; is[e] = a.invstd[cg * EPC + e]; }
+    if (active) {
+        if (MODE == 0) {
+            const int WH = (a.H + 1) / 2, WW = (a.W + 1) / 2;
+            const long long items = (long long)a.N * WH * WW;
+            for (long long r = (long long)blockIdx.x * rpp + phase; r < items; r += (long long)gridDim.x * rpp) {
+                const int pw = (int)(r % WW);
+                const long long t = r / WW;
+                const int ph = (int)(t % WH);
+                const long long n = t / WH;
+                float xf[4][EPC], dz[4][EPC];
+                bool valid[4];
+                dz_window<T>(a, n, ph, pw, cg, xf, valid, dz);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        s1[e] += (double)dz[k][e];
+                        s2[e] += (double)(dz[k][e] * ((xf[k][e] - mu[e]) * is[e]));
+                    }
+            }
+        } else {
+            const long long items = (long long)a.N * a.H * a.W;
+            for (long long r = (long long)blockIdx.x * rpp + phase; r < items; r += (long long)gridDim.x * rpp) {
+                const int w = (int)(r % a.W);
+                const long long t = r / a.W;
+                const int h = (int)(t % a.H);
+                const long long n = t / a.H;
+                float xf[EPC], dz[EPC];
+                load_chunk<T>(x + r * a.C + cg * EPC, xf);
+                dz_at<T, MODE>(a, n, h, w, cg, xf, dz);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    s1[e] += (double)dz[e];
+                    s2[e] += (double)(dz[e] * ((xf[e] - mu[e]) * is[e]));
+                }
+            }
+        }
+    }
+    __shared__ double sm[NT * 2];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        __syncthreads();
+        sm[threadIdx.x] = s1[e];
+        sm[NT + threadIdx.x] = s2[e];
+        __syncthreads();
+        if (active && phase == 0) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int ph = 0; ph < rpp; ++ph) { t1 += sm[ph * G + cg]; t2 += sm[NT + ph * G + cg]; }
+            atomicAdd(&ws[cg * EPC + e], t1);
+            atomicAdd(&ws[a.C + cg * EPC + e], t2);
+        }
+    }
+}
+
+template <typename T, int MODE>
+__global__ void bn_bwd_apply_kernel(BnBwd a, const double* __restrict__ ws, T* __restrict__ dx,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = a.C / EPC;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const double Mtot = (double)a.N * a.H * a.W;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < a.Creal; c += NT) {
+            if (dgamma) dgamma[c] = (float)ws[a.C + c];
+            if (dbeta) dbeta[c] = (float)ws[c];
+        }
+    }
+    if (MODE == 0) {
+        const int WH = (a.H + 1) / 2, WW = (a.W + 1) / 2;
+        const long long total = (long long)a.N * WH * WW * G;
+        for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+            const int cg = (int)(o % G);
+            long long r = o / G;
+            const int pw = (int)(r % WW); r /= WW;
+            const int ph = (int)(r % WH);
+            const long long n = r / WH;
+            float xf[4][EPC], dz[4][EPC];
+            bool valid[4];
+            dz_window<T>(a, n, ph, pw, cg, xf, valid, dz);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!valid[k]) continue;
+                const int h = ph * 2 + (k >> 1), w = pw * 2 + (k & 1);
+                float out[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int c = cg * EPC + e;
+                    const float xh = (xf[k][e] - a.mean[c]) * a.invstd[c];
+                    const float sc = a.scale[c];
+                    if (a.training) {
+                        const float m1 = (float)(ws[c] / Mtot), m2 = (float)(ws[a.C + c] / Mtot);
+                        out[e] = sc * (dz[k][e] - m1 - xh * m2);
+                    } else {
+                        out[e] = sc * dz[k][e];
+                    }
+                }
+                store_chunk<T>(dx + ((n * a.H + h) * a.W + w) * a.C + cg * EPC, out);
+            }
+        }
+    } else {
+        const long long total = (long long)a.N * a.H * a.W * G;
+        for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+            const int cg = (int)(o % G);
+            const long long r = o / G;
+            const int w = (int)(r % a.W);
+            const long long t = r / a.W;
+            const int h = (int)(t % a.H);
+            const long long n = t / a.H;
+            float xf[EPC], dz[EPC], out[EPC];
+            load_chunk<T>(x + o * EPC, xf);
+            dz_at<T, MODE>(a, n, h, w, cg, xf, dz);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = cg * EPC + e;
+                const float xh = (xf[e] - a.mean[c]) * a.invstd[c];
+                if (a.training) {
+                    const float m1 = (float)(ws[c] / Mtot), m2 = (float)(ws[a.C + c] / Mtot);
+                    out[e] = a.scale[c] * (dz[e] - m1 - xh * m2);
+                } else {
+                    out[e] = a.scale[c] * dz[e];
+                }
+            }
+            store_chunk<T>(dx + o * EPC, out);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ bilinear
+struct AxisW { int i0, i1; float l0, l1; };
+__device__ __forceinline__ AxisW axis_w(int dst, int in, int out) {
+    // ATen area_pixel_compute_source_index, align_corners=False, float arithmetic
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    AxisW a;
+    a.i0 = (int)src;
+    if (a.i0 > in - 1) a.i0 = in - 1;
+    a.i1 = a.i0 + (a.i0 < in - 1 ? 1 : 0);
+    a.l1 = src - (float)a.i0;
+    a.l0 = 1.f - a.l1;
+    return a;
+}
+
+// src NHWC f32 [B,h,w,C] -> dst NHWC T [B,OH,OW,C]
+template <typename T>
+__global__ void bilinear_fwd_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int h,
+                                    int w, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = C / EPC;
+    const long long total = (long long)B * OH * OW * G;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int cg = (int)(o % G);
+        long long r = o / G;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const long long b = r / OH;
+        const AxisW ay = axis_w(oy, h, OH), ax = axis_w(ox, w, OW);
+        const float* base = src + b * h * (long long)w * C + cg * EPC;
+        float out[EPC];
+#pragma unroll
+        for (int q = 0; q < EPC; q += 4) {
+            const float4 p00 = *reinterpret_cast<const float4*>(base + ((long long)ay.i0 * w + ax.i0) * C + q);
+            const float4 p01 = *reinterpret_cast<const float4*>(base + ((long long)ay.i0 * w + ax.i1) * C + q);
+            const float4 p10 = *reinterpret_cast<const float4*>(base + ((long long)ay.i1 * w + ax.i0) * C + q);
+            const float4 p11 = *reinterpret_cast<const float4*>(base + ((long long)ay.i1 * w + ax.i1) * C + q);
+            const float* a00 = &p00.x; const float* a01 = &p01.x; const float* a10 = &p10.x; const float* a11 = &p11.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                out[q + e] = ay.l0 * (ax.l0 * a00[e] + ax.l1 * a01[e]) + ay.l1 * (ax.l0 * a10[e] + ax.l1 * a11[e]);
+        }
+        store_chunk<T>(dst + o * EPC, out);
+    }
+}
+
+// pass 1: tmp[b][oy][sx][c] = sum_ox wx(ox -> sx) * ddst[b][oy][ox][c]
+template <typename T>
+__global__ void bilinear_bwd_x_kernel(const T* __restrict__ ddst, float* __restrict__ tmp, int B, int C, int w,
+                                      int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int G = C / EPC;
+    const long long total = (long long)B * OH * w * G;
+    const float inv_scale = (float)OW / (float)w;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int cg = (int)(o % G);
+        long long r = o / G;
+        const int sx = (int)(r % w); r /= w;  // r = b*OH + oy
+        int lo = (int)floorf(((float)sx - 0.5f) * inv_scale - 0.5f) - 2; if (lo < 0) lo = 0;
+        int hi = (int)ceilf(((float)sx + 1.5f) * inv_scale - 0.5f) + 2; if (hi > OW - 1) hi = OW - 1;
+        if (sx == 0) lo = 0;
+        if (sx == w - 1) hi = OW - 1;
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (int ox = lo; ox <= hi; ++ox) {
+            const AxisW a = axis_w(ox, w, OW);
+            const float wt = (a.i0 == sx ? a.l0 : 0.f) + (a.i1 == sx ? a.l1 : 0.f);
+            if (wt == 0.f) continue;
+            float f[EPC];
+            load_chunk<T>(ddst + (r * OW + ox) * C + cg * EPC, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += wt * f[e];
+        }
+#pragma unroll
+        for (int q = 0; q < EPC; q += 4)
+            *reinterpret_cast<float4*>(tmp + (r * w + sx) * C + cg * EPC + q) =
+                make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+    }
+}
+
+// pass 2: dsrc[b][sy][sx][c] (NHWC f32) = sum_oy wy(oy -> sy) * tmp[b][oy][sx][c]
+__global__ void bilinear_bwd_y_kernel(const float* __restrict__ tmp, float* __restrict__ dsrc, int B, int C,
+                                      int h, int w, int OH) {
+    const int G = C / 4;
+    const long long total = (long long)B * h * w * G;
+    const float inv_scale = (float)OH / (float)h;
+    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
+        const int cg = (int)(o % G);
+        long long r = o / G;
+        const int sx = (int)(r % w); r /= w;
+        const int sy = (int)(r % h);
+        const long long b = r / h;
+        int lo = (int)floorf(((float)sy - 0.5f) * inv_scale - 0.5f) - 2; if (lo < 0) lo = 0;
+        int hi = (int)ceilf(((float)sy + 1.5f) * inv_scale - 0.5f) + 2; if (hi > OH - 1) hi = OH - 1;
+        if (sy == 0) lo = 0;
+        if (sy == h - 1) hi = OH - 1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = lo; oy <= hi; ++oy) {
+            const AxisW a = axis_w(oy, h, OH);
+            const float wt = (a.i0 == sy ? a.l0 : 0.f) + (a.i1 == sy ? a.l1 : 0.f);
+            if (wt == 0.f) continue;
+            const float4 f = *reinterpret_cast<const float4*>(tmp + ((b * OH + oy) * w + sx) * (long long)C + cg * 4);
+            acc.x += wt * f.x; acc.y += wt * f.y; acc.z += wt * f.z; acc.w += wt * f.w;
+        }
+        *reinterpret_cast<float4*>(dsrc + o * 4) = acc;
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                       \
+    if ((dtype) == SF_BF16) { using T = bf16; CALL; }                 \
+    else if ((dtype) == SF_F32) { using T = float; CALL; }            \
+    else { sf_set_error("bad dtype %d", (int)(dtype)); return SF_EINVAL; }
+
+extern "C" int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad,
+                               void* stream) {
+    SF_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "sf_nchw_to_nhwc: bad arguments");
+    SF_REQUIRE(Cpad % (dtype == SF_BF16 ? 8 : 4) == 0, "sf_nchw_to_nhwc: Cpad=%d not a chunk multiple", Cpad);
+    const long long npix = (long long)N * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(npix)), dim3(NT), 0,
+                                         (hipStream_t)stream, in, (T*)out, npix, C, H * W, Cpad));
+    SF_LAUNCH_CHECK("sf_nchw_to_nhwc");
+    return SF_OK;
+}
+
+extern "C" int sf_nhwc_to_nchw(const void* in, int dtype, float* out, int N, int C, int H, int W, int Cpad,
+                               void* stream) {
+    SF_REQUIRE(in && out && N > 0 && C > 0 && Cpad >= C, "sf_nhwc_to_nchw: bad arguments");
+    const long long total = (long long)N * C * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for(total)), dim3(NT), 0,
+                                         (hipStream_t)stream, (const T*)in, out, total, C, H * W, Cpad));
+    SF_LAUNCH_CHECK("sf_nhwc_to_nchw");
+    return SF_OK;
+}
+
+extern "C" int sf_pack_conv_weight(const float* w, void* out, int dtype, int O, int I, int RS, int transpose,
+                                   int ntaps, const int* tap_rs, int rows_pad, int cols_pad, void* stream) {
+    SF_REQUIRE(w && out && tap_rs && ntaps >= 1 && ntaps <= 16, "sf_pack_conv_weight: bad arguments");
+    SF_REQUIRE(rows_pad >= (transpose ? I : O) && cols_pad >= (transpose ? O : I), "sf_pack_conv_weight: padding smaller than the tensor");
+    PackArgs a;
+    a.O = O; a.I = I; a.RS = RS; a.transpose = transpose; a.ntaps = ntaps; a.rows_pad = rows_pad; a.cols_pad = cols_pad;
+    for (int t = 0; t < 16; ++t) a.tap_rs[t] = t < ntaps ? tap_rs[t] : 0;
+    for (int t = 0; t < ntaps; ++t) SF_REQUIRE(tap_rs[t] >= 0 && tap_rs[t] < RS, "sf_pack_conv_weight: tap outside the filter");
+    const long long total = (long long)rows_pad * ntaps * cols_pad;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(grid_for(total)), dim3(NT), 0,
+                                         (hipStream_t)stream, w, (T*)out, a));
+    SF_LAUNCH_CHECK("sf_pack_conv_weight");
+    return SF_OK;
+}
+
+extern "C" int sf_cast(const float* in, void* out, int dtype, long long n, void* stream) {
+    SF_REQUIRE(in && out && n > 0, "sf_cast: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(cast_kernel<T>, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, in,
+                                         (T*)out, n));
+    SF_LAUNCH_CHECK("sf_cast");
+    return SF_OK;
+}
+
+static int check_chunked(const char* who, int dtype, int C) {
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    if (C <= 0 || C % epc != 0) {
+        sf_set_error("%s: channel count %d must be a positive multiple of %d", who, C, epc);
+        return SF_EINVAL;
+    }
+    if (C / epc > NT) {
+        sf_set_error("%s: channel count %d too wide", who, C);
+        return SF_EINVAL;
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_bn_stats(const void* x, int dtype, long long M, int C, double* ws, void* stream) {
+    SF_REQUIRE(x && ws && M > 0, "sf_bn_stats: bad arguments");
+    if (int rc = check_chunked("sf_bn_stats", dtype, C)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { sf_set_error("sf_bn_stats: memset failed"); return SF_ELAUNCH; }
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
+    int grid = (int)((M + rpp - 1) / rpp); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, true>), dim3(grid), dim3(NT), 0, s, (const T*)x, M, C, ws));
+    SF_LAUNCH_CHECK("sf_bn_stats");
+    return SF_OK;
+}
+
+namespace {
+__global__ void ws_to_float_kernel(const double* ws, float* out, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (float)ws[i];
+}
+}  // namespace
+
+extern "C" int sf_channel_sum(const void* x, int dtype, long long M, int C, int Creal, float* out, double* ws,
+                                 void* stream) {
+    SF_REQUIRE(x && out && ws && M > 0 && Creal <= C, "sf_channel_sum: bad arguments");
+    if (int rc = check_chunked("sf_channel_sum", dtype, C)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * C, s) != hipSuccess) { sf_set_error("sf_channel_sum: memset failed"); return SF_ELAUNCH; }
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
+    int grid = (int)((M + rpp - 1) / rpp); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, false>), dim3(grid), dim3(NT), 0, s, (const T*)x, M, C, ws));
+    hipLaunchKernelGGL(ws_to_float_kernel, dim3(1), dim3(NT), 0, s, ws, out, Creal);
+    SF_LAUNCH_CHECK("sf_channel_sum");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_finalize(const double* ws, long long M, int C, int Creal, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int training,
+                              float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    SF_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && mean && invstd, "sf_bn_finalize: null argument");
+    SF_REQUIRE(!training || (ws && M > 0), "sf_bn_finalize: training needs statistics");
+    SF_REQUIRE(Creal <= C && C > 0, "sf_bn_finalize: bad channel counts");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, ws, M, C, Creal, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, scale, shift, mean, invstd);
+    SF_LAUNCH_CHECK("sf_bn_finalize");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_relu_maxpool_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
+                                      int N, int H, int W, int C, void* stream) {
+    SF_REQUIRE(x && y && scale && shift && N > 0 && H >= 2 && W >= 2, "sf_bn_relu_maxpool_fwd: bad arguments");
+    if (int rc = check_chunked("sf_bn_relu_maxpool_fwd", dtype, C)) return rc;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<T>, dim3(grid_for(total, 8192)), dim3(NT), 0,
+                                         (hipStream_t)stream, (const T*)x, scale, shift, (T*)y, N, H, W, C));
+    SF_LAUNCH_CHECK("sf_bn_relu_maxpool_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_relu_avgpool_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
+                                      int out_dtype, int N, int H, int W, int C, int Creal, int OH, int OW,
+                                      void* stream) {
+    SF_REQUIRE(x && y && scale && shift && N > 0 && OH > 0 && OW > 0 && Creal <= C, "sf_bn_relu_avgpool_fwd: bad arguments");
+    if (int rc = check_chunked("sf_bn_relu_avgpool_fwd", dtype, C)) return rc;
+    SF_REQUIRE(OW <= 128, "sf_bn_relu_avgpool_fwd: OW=%d > 128", OW);
+    const size_t lds = sizeof(float) * 128 * (OW + 1);
+    dim3 grid((unsigned)(N * OH)), block(NT);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SF_BF16 && out_dtype == SF_BF16)
+        hipLaunchKernelGGL((bn_relu_avgpool_fwd_kernel<bf16, bf16>), grid, block, lds, s, (const bf16*)x, scale, shift, (bf16*)y, N, H, W, C, Creal, OH, OW);
+    else if (dtype == SF_BF16 && out_dtype == SF_F32)
+        hipLaunchKernelGGL((bn_relu_avgpool_fwd_kernel<bf16, float>), grid, block, lds, s, (const bf16*)x, scale, shift, (float*)y, N, H, W, C, Creal, OH, OW);
+    else if (dtype == SF_F32 && out_dtype == SF_F32)
+        hipLaunchKernelGGL((bn_relu_avgpool_fwd_kernel<float, float>), grid, block, lds, s, (const float*)x, scale, shift, (float*)y, N, H, W, C, Creal, OH, OW);
+    else { sf_set_error("sf_bn_relu_avgpool_fwd: unsupported dtype pair %d -> %d", dtype, out_dtype); return SF_EINVAL; }
+    SF_LAUNCH_CHECK("sf_bn_relu_avgpool_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_lrelu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
+                               long long M, int C, void* stream) {
+    SF_REQUIRE(x && y && scale && shift && M > 0, "sf_bn_lrelu_fwd: bad arguments");
+    if (int rc = check_chunked("sf_bn_lrelu_fwd", dtype, C)) return rc;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_lrelu_fwd_kernel<T>, dim3(grid_for(M * (C / epc), 8192)), dim3(NT), 0,
+                                         (hipStream_t)stream, (const T*)x, scale, shift, (T*)y, M, C));
+    SF_LAUNCH_CHECK("sf_bn_lrelu_fwd");
+    return SF_OK;
+}
+
+static int fill_bnbwd(BnBwd& a, int mode, const void* x, const void* dy, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, const float* gamma, int N, int H, int W, int C,
+                      int Creal, int OH, int OW, int training, int dtype, int dy_dtype) {
+    SF_REQUIRE(mode >= 0 && mode <= 2, "bn_bwd: bad mode %d", mode);
+    SF_REQUIRE(x && dy && scale && shift && mean && invstd, "bn_bwd: null argument");
+    SF_REQUIRE(dy_dtype == dtype, "bn_bwd: dy dtype must equal x dtype");
+    SF_REQUIRE(N > 0 && H > 0 && W > 0 && Creal <= C, "bn_bwd: bad shape");
+    if (mode == 1) SF_REQUIRE(OH > 0 && OW > 0, "bn_bwd: avgpool mode needs OH, OW");
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    SF_REQUIRE(C % epc == 0 && C / epc <= NT, "bn_bwd: channel count %d unsupported", C);
+    a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.Creal = Creal; a.OH = OH; a.OW = OW; a.training = training;
+    return SF_OK;
+}
+
+extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* dy, int dy_dtype, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, double* ws, int N, int H,
+                                int W, int C, int Creal, int OH, int OW, void* stream) {
+    BnBwd a;
+    if (int rc = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, scale, N, H, W, C, Creal, OH, OW, 1, dtype, dy_dtype)) return rc;
+    SF_REQUIRE(ws, "sf_bn_bwd_reduce: null workspace");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { sf_set_error("sf_bn_bwd_reduce: memset failed"); return SF_ELAUNCH; }
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
+    const long long items = mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
+    int grid = (int)((items + rpp - 1) / rpp); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+#define RED(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), dim3(grid), dim3(NT), 0, s, a, ws))
+    if (mode == 0) { RED(0); } else if (mode == 1) { RED(1); } else { RED(2); }
+#undef RED
+    SF_LAUNCH_CHECK("sf_bn_bwd_reduce");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* dy, int dy_dtype, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* gamma,
+                               const double* ws, int training, void* dx, float* dgamma, float* dbeta, int N, int H,
+                               int W, int C, int Creal, int OH, int OW, void* stream) {
+    BnBwd a;
+    if (int rc = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, gamma ? gamma : scale, N, H, W, C, Creal, OH, OW, training, dtype, dy_dtype)) return rc;
+    SF_REQUIRE(ws && dx, "sf_bn_bwd_apply: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const long long items = (mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W) * (C / epc);
+    const int grid = grid_for(items, 8192);
+#define APP(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MODE>), dim3(grid), dim3(NT), 0, s, a, ws, (T*)dx, dgamma, dbeta))
+    if (mode == 0) { APP(0); } else if (mode == 1) { APP(1); } else { APP(2); }
+#undef APP
+    SF_LAUNCH_CHECK("sf_bn_bwd_apply");
+    return SF_OK;
+}
+
+extern "C" int sf_bilinear_fwd(const void* src, int src_dtype, void* dst, int dtype, int B, int C, int h, int w,
+                               int OH, int OW, int Cpad, void* stream) {
+    SF_REQUIRE(src && dst && B > 0 && h > 0 && w > 0 && OH > 0 && OW > 0, "sf_bilinear_fwd: bad arguments");
+    SF_REQUIRE(src_dtype == SF_F32, "sf_bilinear_fwd: source must be NHWC f32");
+    SF_REQUIRE(C == Cpad && Cpad % (dtype == SF_BF16 ? 8 : 4) == 0, "sf_bilinear_fwd: C=%d must equal Cpad and be a chunk multiple", C);
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const long long total = (long long)B * OH * OW * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(grid_for(total, 16384)), dim3(NT), 0,
+                                         (hipStream_t)stream, (const float*)src, (T*)dst, B, C, h, w, OH, OW));
+    SF_LAUNCH_CHECK("sf_bilinear_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_bilinear_bwd(const void* ddst, int dtype, float* dsrc, float* tmp, int B, int C, int h, int w,
+                               int OH, int OW, int Cpad, void* stream) {
+    SF_REQUIRE(ddst && dsrc && tmp && B > 0, "sf_bilinear_bwd: bad arguments");
+    SF_REQUIRE(C == Cpad && Cpad % (dtype == SF_BF16 ? 8 : 4) == 0, "sf_bilinear_bwd: C must equal Cpad and be a chunk multiple");
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    hipStream_t s = (hipStream_t)stream;
+    const long long t1 = (long long)B * OH * w * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_x_kernel<T>, dim3(grid_for(t1, 16384)), dim3(NT), 0, s,
+                                         (const T*)ddst, tmp, B, C, w, OH, OW));
+    const long long t2 = (long long)B * h * w * (C / 4);
+    hipLaunchKernelGGL(bilinear_bwd_y_kernel, dim3(grid_for(t2, 16384)), dim3(NT), 0, s, tmp, dsrc, B, C, h, w, OH);
+    SF_LAUNCH_CHECK("sf_bilinear_bwd");
+    return SF_OK;
+}

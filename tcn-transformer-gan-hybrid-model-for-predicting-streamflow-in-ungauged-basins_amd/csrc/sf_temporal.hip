@@ -1,0 +1,626 @@
+// Temporal modules over the short day window: one workgroup per sample keeps the whole
+// [T<=8, D<=128] sequence in LDS, so a Transformer encoder layer (or the LSTM stack) is a
+// single launch forward and a single launch backward.  LayerNorm / softmax statistics use
+// wavefront reductions.  All arithmetic is f32.
+#include "sf_common.h"
+#include "../../include/sfhip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXT = 8;
+
+struct Ptrs12 { const float* p[12]; };
+struct MPtrs12 { float* p[12]; };
+struct Ptrs16 { const float* p[16]; };
+struct MPtrs16 { float* p[16]; };
+
+__device__ __forceinline__ float rand_u(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+// multiplicative dropout mask value (0 or 1/(1-p)) for element i of site s of sample b
+__device__ __forceinline__ float drop_mask(float p, unsigned long long seed, int b, int site, int i) {
+    if (p <= 0.f) return 1.f;
+    const unsigned long long idx = ((unsigned long long)b * 16ull + (unsigned long long)site) * 65536ull + (unsigned long long)i;
+    return rand_u(seed, idx) >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+__device__ __forceinline__ float dot_row(const float* __restrict__ wrow, const float* __restrict__ v, int n) {
+    float a = 0.f;
+    for (int d = 0; d < n; d += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(wrow + d);
+        a += w.x * v[d] + w.y * v[d + 1] + w.z * v[d + 2] + w.w * v[d + 3];
+    }
+    return a;
+}
+
+// save layout (floats per sample)
+struct TrSave {
+    int qkv, probs, ctx, xhat1, rstd1, x1, hd, xhat2, rstd2, total;
+    __host__ __device__ TrSave(int T, int D, int F) {
+        int o = 0;
+        qkv = o; o += T * 3 * D;
+        probs = o; o += 8 * T * T;
+        ctx = o; o += T * D;
+        xhat1 = o; o += T * D;
+        rstd1 = o; o += MAXT;
+        x1 = o; o += T * D;
+        hd = o; o += T * F;
+        xhat2 = o; o += T * D;
+        rstd2 = o; o += MAXT;
+        total = (o + 3) & ~3;
+    }
+};
+
+// LayerNorm over D for every token of `in` (LDS); wave w handles tokens w, w+4.
+__device__ __forceinline__ void layer_norm_tokens(const float* in, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* out, float* xhat_g,
+                                                  float* rstd_g, int T, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < T; t += 4) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += in[t * D + d];
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+        for (int d = lane; d < D; d += 64) { const float c = in[t * D + d] - mean; q += c * c; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+        for (int d = lane; d < D; d += 64) {
+            const float xh = (in[t * D + d] - mean) * rstd;
+            if (xhat_g) xhat_g[t * D + d] = xh;
+            out[t * D + d] = xh * gamma[d] + beta[d];
+        }
+        if (rstd_g && lane == 0) rstd_g[t] = rstd;
+    }
+}
+
+__global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             Ptrs12 W, float* __restrict__ save, int T, int D,
+                                                             int F, int nh, float p, unsigned long long seed) {
+    extern __shared__ float sm[];
+    float* xs = sm;                 // [T][D]
+    float* qkv = xs + T * D;        // [T][3D]
+    float* pr = qkv + T * 3 * D;    // [nh][T][T]
+    float* ctx = pr + 8 * T * T;    // [T][D]
+    float* x1 = ctx + T * D;        // [T][D]
+    float* hd = x1 + T * D;         // [T][F]
+    float* tmp = hd + T * F;        // [T][D]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const TrSave L(T, D, F);
+    float* sv = save ? save + (size_t)b * L.total : nullptr;
+    const int hdm = D / nh;
+    const float* Win = W.p[0]; const float* bin = W.p[1]; const float* Wo = W.p[2]; const float* bo = W.p[3];
+    const float* W1 = W.p[4]; const float* b1 = W.p[5]; const float* W2 = W.p[6]; const float* b2 = W.p[7];
+
+    for (int i = tid; i < T * D; i += NT) xs[i] = x[(size_t)b * T * D + i];
+    __syncthreads();
+    // packed q,k,v projection
+    for (int o = tid; o < 3 * D; o += NT) {
+        const float bb = bin[o];
+        for (int t = 0; t < T; ++t) {
+            const float v = dot_row(Win + (size_t)o * D, xs + t * D, D) + bb;
+            qkv[t * 3 * D + o] = v;
+            if (sv) sv[L.qkv + t * 3 * D + o] = v;
+        }
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)hdm);
+    for (int i = tid; i < nh * T * T; i += NT) {
+        const int s = i % T, t = (i / T) % T, h = i / (T * T);
+        float a = 0.f;
+        for (int j = 0; j < hdm; ++j) a += qkv[t * 3 * D + h * hdm + j] * qkv[s * 3 * D + D + h * hdm + j];
+        pr[i] = a * scale;
+    }
+    __syncthreads();
+    for (int i = tid; i < nh * T; i += NT) {  // softmax over s for row (h,t)
+        float* row = pr + i * T;
+        float m = row[0];
+        for (int s = 1; s < T; ++s) m = fmaxf(m, row[s]);
+        float den = 0.f;
+        for (int s = 0; s < T; ++s) { row[s] = expf(row[s] - m); den += row[s]; }
+        const float inv = 1.0f / den;
+        for (int s = 0; s < T; ++s) {
+            const float pv = row[s] * inv;
+            if (sv) sv[L.probs + i * T + s] = pv;
+            row[s] = pv * drop_mask(p, seed, b, 0, i * T + s);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < T * D; i += NT) {
+        const int d = i % D, t = i / D, h = d / hdm;
+        float a = 0.f;
+        for (int s = 0; s < T; ++s) a += pr[(h * T + t) * T + s] * qkv[s * 3 * D + 2 * D + d];
+        ctx[i] = a;
+        if (sv) sv[L.ctx + i] = a;
+    }
+    __syncthreads();
+    for (int o = tid; o < D; o += NT) {
+        const float bb = bo[o];
+        for (int t = 0; t < T; ++t) {
+            const float v = dot_row(Wo + (size_t)o * D, ctx + t * D, D) + bb;
+            tmp[t * D + o] = xs[t * D + o] + v * drop_mask(p, seed, b, 1, t * D + o);
+        }
+    }
+    __syncthreads();
+    layer_norm_tokens(tmp, W.p[8], W.p[9], x1, sv ? sv + L.xhat1 : nullptr, sv ? sv + L.rstd1 : nullptr, T, D);
+    __syncthreads();
+    if (sv) for (int i = tid; i < T * D; i += NT) sv[L.x1 + i] = x1[i];
+    for (int f = tid; f < F; f += NT) {
+        const float bb = b1[f];
+        for (int t = 0; t < T; ++t) {
+            float v = dot_row(W1 + (size_t)f * D, x1 + t * D, D) + bb;
+            v = v > 0.f ? v * drop_mask(p, seed, b, 2, t * F + f) : 0.f;
+            hd[t * F + f] = v;
+            if (sv) sv[L.hd + t * F + f] = v;
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < D; o += NT) {
+        const float bb = b2[o];
+        for (int t = 0; t < T; ++t) {
+            const float v = dot_row(W2 + (size_t)o * F, hd + t * F, F) + bb;
+            tmp[t * D + o] = x1[t * D + o] + v * drop_mask(p, seed, b, 3, t * D + o);
+        }
+    }
+    __syncthreads();
+    layer_norm_tokens(tmp, W.p[10], W.p[11], xs, sv ? sv + L.xhat2 : nullptr, sv ? sv + L.rstd2 : nullptr, T, D);
+    __syncthreads();
+    for (int i = tid; i < T * D; i += NT) y[(size_t)b * T * D + i] = xs[i];
+}
+
+// LayerNorm backward for every token: g (LDS, gradient wrt LN output) -> out (gradient wrt LN input)
+__device__ __forceinline__ void layer_norm_bwd_tokens(const float* g, const float* __restrict__ gamma,
+                                                      const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                      float* out, int T, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < T; t += 4) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float gy = g[t * D + d] * gamma[d];
+            s1 += gy;
+            s2 += gy * xhat[t * D + d];
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+        const float r = rstd[t];
+        for (int d = lane; d < D; d += 64) {
+            const float gy = g[t * D + d] * gamma[d];
+            out[t * D + d] = r * (gy - m1 - xhat[t * D + d] * m2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ dx, Ptrs12 W, MPtrs12 G,
+                                                             const float* __restrict__ save, int T, int D, int F,
+                                                             int nh, float p, unsigned long long seed) {
+    extern __shared__ float sm[];
+    float* g0 = sm;                 // [T][D]
+    float* g1 = g0 + T * D;         // [T][D]
+    float* gF = g1 + T * D;         // [T][F]  (also d_ctx)
+    float* gq = gF + T * F;         // [T][3D]
+    float* gp = gq + T * 3 * D;     // [nh][T][T]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const TrSave L(T, D, F);
+    const float* sv = save + (size_t)b * L.total;
+    const float* xin = x + (size_t)b * T * D;
+    const int hdm = D / nh;
+    const float* Win = W.p[0]; const float* Wo = W.p[2]; const float* W1 = W.p[4]; const float* W2 = W.p[6];
+
+    for (int i = tid; i < T * D; i += NT) g0[i] = dy[(size_t)b * T * D + i];
+    __syncthreads();
+    // ---- LayerNorm 2
+    for (int d = tid; d < D; d += NT) {
+        float a = 0.f, c = 0.f;
+        for (int t = 0; t < T; ++t) { a += g0[t * D + d] * sv[L.xhat2 + t * D + d]; c += g0[t * D + d]; }
+        atomicAdd(G.p[10] + d, a);
+        atomicAdd(G.p[11] + d, c);
+    }
+    layer_norm_bwd_tokens(g0, W.p[10], sv + L.xhat2, sv + L.rstd2, g1, T, D);
+    __syncthreads();
+    // g1 = grad wrt (x1 + ff); d_ff = g1 * mask2 -> g0
+    for (int i = tid; i < T * D; i += NT) g0[i] = g1[i] * drop_mask(p, seed, b, 3, i);
+    __syncthreads();
+    // linear2: dW2[o][f], db2[o]
+    for (int i = tid; i < D * F; i += NT) {
+        const int f = i % F, o = i / F;
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += g0[t * D + o] * sv[L.hd + t * F + f];
+        atomicAdd(G.p[6] + i, a);
+    }
+    for (int o = tid; o < D; o += NT) {
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += g0[t * D + o];
+        atomicAdd(G.p[7] + o, a);
+    }
+    // d_hidden -> pre-activation gradient (ReLU and dropout share the saved value's sign)
+    for (int f = tid; f < F; f += NT) {
+        float acc[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
+        for (int o = 0; o < D; ++o) {
+            const float w = W2[(size_t)o * F + f];
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += g0[t * D + o] * w;
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (t < T) {
+                const float keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+                gF[t * F + f] = sv[L.hd + t * F + f] > 0.f ? acc[t] * keep : 0.f;
+            }
+    }
+    __syncthreads();
+    // linear1: dW1[f][d], db1[f]; d_x1 += dz . W1
+    for (int i = tid; i < F * D; i += NT) {
+        const int d = i % D, f = i / D;
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += gF[t * F + f] * sv[L.x1 + t * D + d];
+        atomicAdd(G.p[4] + i, a);
+    }
+    for (int f = tid; f < F; f += NT) {
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += gF[t * F + f];
+        atomicAdd(G.p[5] + f, a);
+    }
+    for (int d = tid; d < D; d += NT) {
+        float acc[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float w = W1[(size_t)f * D + d];
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += gF[t * F + f] * w;
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) if (t < T) g1[t * D + d] += acc[t];
+    }
+    __syncthreads();
+    // ---- LayerNorm 1 (g1 = gradient wrt x1)
+    for (int d = tid; d < D; d += NT) {
+        float a = 0.f, c = 0.f;
+        for (int t = 0; t < T; ++t) { a += g1[t * D + d] * sv[L.xhat1 + t * D + d]; c += g1[t * D + d]; }
+        atomicAdd(G.p[8] + d, a);
+        atomicAdd(G.p[9] + d, c);
+    }
+    layer_norm_bwd_tokens(g1, W.p[8], sv + L.xhat1, sv + L.rstd1, g0, T, D);
+    __syncthreads();
+    // g0 = gradient wrt (x + sa); d_sa = g0 * mask1 -> g1
+    for (int i = tid; i < T * D; i += NT) g1[i] = g0[i] * drop_mask(p, seed, b, 1, i);
+    __syncthreads();
+    // out_proj: dWo[o][j], dbo[o]; d_ctx -> gF[0 : T*D]
+    for (int i = tid; i < D * D; i += NT) {
+        const int j = i % D, o = i / D;
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += g1[t * D + o] * sv[L.ctx + t * D + j];
+        atomicAdd(G.p[2] + i, a);
+    }
+    for (int o = tid; o < D; o += NT) {
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += g1[t * D + o];
+        atomicAdd(G.p[3] + o, a);
+    }
+    for (int j = tid; j < D; j += NT) {
+        float acc[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
+        for (int o = 0; o < D; ++o) {
+            const float w = Wo[(size_t)o * D + j];
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += g1[t * D + o] * w;
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) if (t < T) gF[t * D + j] = acc[t];
+    }
+    __syncthreads();
+    // ---- attention: d_pused = d_ctx . v
+    const float* qkv = sv + L.qkv;
+    for (int i = tid; i < nh * T * T; i += NT) {
+        const int s = i % T, t = (i / T) % T, h = i / (T * T);
+        float a = 0.f;
+        for (int j = 0; j < hdm; ++j) a += gF[t * D + h * hdm + j] * qkv[s * 3 * D + 2 * D + h * hdm + j];
+        gp[i] = a;
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)hdm);
+    for (int i = tid; i < nh * T; i += NT) {  // softmax backward per row (h,t)
+        float dp[MAXT];
+        float dot = 0.f;
+        for (int s = 0; s < T; ++s) {
+            dp[s] = gp[i * T + s] * drop_mask(p, seed, b, 0, i * T + s);
+            dot += dp[s] * sv[L.probs + i * T + s];
+        }
+        for (int s = 0; s < T; ++s) gp[i * T + s] = sv[L.probs + i * T + s] * (dp[s] - dot) * scale;
+    }
+    __syncthreads();
+    for (int i = tid; i < T * D; i += NT) {
+        const int d = i % D, t = i / D, h = d / hdm;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int s = 0; s < T; ++s) {
+            dq += gp[(h * T + t) * T + s] * qkv[s * 3 * D + D + d];
+            dk += gp[(h * T + s) * T + t] * qkv[s * 3 * D + d];
+            const float pu = sv[L.probs + (h * T + s) * T + t] * drop_mask(p, seed, b, 0, (h * T + s) * T + t);
+            dv += pu * gF[s * D + d];
+        }
+        gq[t * 3 * D + d] = dq;
+        gq[t * 3 * D + D + d] = dk;
+        gq[t * 3 * D + 2 * D + d] = dv;
+    }
+    __syncthreads();
+    // in_proj: dWin[o][d], dbin[o]; dx = g0 + gq . Win
+    for (int i = tid; i < 3 * D * D; i += NT) {
+        const int d = i % D, o = i / D;
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += gq[t * 3 * D + o] * xin[t * D + d];
+        atomicAdd(G.p[0] + i, a);
+    }
+    for (int o = tid; o < 3 * D; o += NT) {
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += gq[t * 3 * D + o];
+        atomicAdd(G.p[1] + o, a);
+    }
+    for (int d = tid; d < D; d += NT) {
+        float acc[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
+        for (int o = 0; o < 3 * D; ++o) {
+            const float w = Win[(size_t)o * D + d];
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += gq[t * 3 * D + o] * w;
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) if (t < T) dx[(size_t)b * T * D + t * D + d] = g0[t * D + d] + acc[t];
+    }
+}
+
+__global__ void add_pe_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ y,
+                              long long total, int TD) {
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT)
+        y[i] = x[i] + pe[i % TD];
+}
+__global__ void mean_t_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int T, int D) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < B * D; i += gridDim.x * NT) {
+        const int d = i % D, b = i / D;
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += x[((size_t)b * T + t) * D + d];
+        y[i] = a / (float)T;
+    }
+}
+__global__ void mean_t_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int T, int D) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < B * T * D; i += gridDim.x * NT) {
+        const int d = i % D, b = i / (T * D);
+        dx[i] = dy[b * D + d] / (float)T;
+    }
+}
+
+// ------------------------------------------------------------------------------ LSTM
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ __launch_bounds__(NT) void lstm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, Ptrs16 W,
+                                                      float* __restrict__ save, int T, int H, int L, float p,
+                                                      unsigned long long seed) {
+    extern __shared__ float sm[];
+    float* xin = sm;             // [T][H]
+    float* hs = xin + T * H;     // [T][H]
+    float* h = hs + T * H;       // [H]
+    float* c = h + H;            // [H]
+    float* gates = c + H;        // [4H]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* sv = save ? save + (size_t)b * T * L * 6 * H : nullptr;
+    for (int i = tid; i < T * H; i += NT) xin[i] = x[(size_t)b * T * H + i];
+    for (int l = 0; l < L; ++l) {
+        const float* Wih = W.p[4 * l]; const float* Whh = W.p[4 * l + 1];
+        const float* bih = W.p[4 * l + 2]; const float* bhh = W.p[4 * l + 3];
+        for (int i = tid; i < H; i += NT) { h[i] = 0.f; c[i] = 0.f; }
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            for (int r = tid; r < 4 * H; r += NT)
+                gates[r] = bih[r] + bhh[r] + dot_row(Wih + (size_t)r * H, xin + t * H, H) + dot_row(Whh + (size_t)r * H, h, H);
+            __syncthreads();
+            for (int j = tid; j < H; j += NT) {
+                const float ig = sigmoidf_(gates[j]), fg = sigmoidf_(gates[H + j]);
+                const float gg = tanhf(gates[2 * H + j]), og = sigmoidf_(gates[3 * H + j]);
+                const float cn = fg * c[j] + ig * gg;
+                const float hn = og * tanhf(cn);
+                c[j] = cn; h[j] = hn; hs[t * H + j] = hn;
+                if (sv) {
+                    float* s = sv + ((size_t)l * T + t) * 6 * H;
+                    s[j] = ig; s[H + j] = fg; s[2 * H + j] = gg; s[3 * H + j] = og; s[4 * H + j] = cn; s[5 * H + j] = hn;
+                }
+            }
+            __syncthreads();
+        }
+        if (l + 1 < L) {
+            for (int i = tid; i < T * H; i += NT) xin[i] = hs[i] * drop_mask(p, seed, b, l, i);
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < H; j += NT) y[(size_t)b * H + j] = h[j];
+}
+
+__global__ __launch_bounds__(NT) void lstm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, Ptrs16 W, MPtrs16 G,
+                                                      const float* __restrict__ save, int T, int H, int L, float p,
+                                                      unsigned long long seed) {
+    extern __shared__ float sm[];
+    float* dext = sm;              // [T][H] external gradient on this layer's outputs
+    float* dxin = dext + T * H;    // [T][H] gradient wrt this layer's inputs
+    float* dG = dxin + T * H;      // [T][4H] pre-activation gate gradients
+    float* dh = dG + T * 4 * H;    // [H]
+    float* dc = dh + H;            // [H]
+    float* xin = dc + H;           // [T][H] this layer's inputs
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* sv = save + (size_t)b * T * L * 6 * H;
+    for (int i = tid; i < T * H; i += NT) dext[i] = (i / H == T - 1) ? dy[(size_t)b * H + i % H] : 0.f;
+    __syncthreads();
+    for (int l = L - 1; l >= 0; --l) {
+        const float* Wih = W.p[4 * l]; const float* Whh = W.p[4 * l + 1];
+        for (int i = tid; i < T * H; i += NT) {
+            if (l == 0) xin[i] = x[(size_t)b * T * H + i];
+            else xin[i] = sv[((size_t)(l - 1) * T + i / H) * 6 * H + 5 * H + i % H] * drop_mask(p, seed, b, l - 1, i);
+        }
+        for (int i = tid; i < H; i += NT) { dh[i] = 0.f; dc[i] = 0.f; }
+        __syncthreads();
+        for (int t = T - 1; t >= 0; --t) {
+            const float* s = sv + ((size_t)l * T + t) * 6 * H;
+            for (int j = tid; j < H; j += NT) {
+                const float ig = s[j], fg = s[H + j], gg = s[2 * H + j], og = s[3 * H + j], cn = s[4 * H + j];
+                const float cprev = t > 0 ? sv[((size_t)l * T + t - 1) * 6 * H + 4 * H + j] : 0.f;
+                const float dht = dext[t * H + j] + dh[j];
+                const float tc = tanhf(cn);
+                const float dct = dc[j] + dht * og * (1.f - tc * tc);
+                dG[t * 4 * H + j] = dct * gg * ig * (1.f - ig);
+                dG[t * 4 * H + H + j] = dct * cprev * fg * (1.f - fg);
+                dG[t * 4 * H + 2 * H + j] = dct * ig * (1.f - gg * gg);
+                dG[t * 4 * H + 3 * H + j] = dht * tc * og * (1.f - og);
+                dc[j] = dct * fg;
+            }
+            __syncthreads();
+            for (int j = tid; j < H; j += NT) {
+                float a = 0.f, r2 = 0.f;
+                for (int r = 0; r < 4 * H; ++r) {
+                    const float g = dG[t * 4 * H + r];
+                    a += Wih[(size_t)r * H + j] * g;
+                    r2 += Whh[(size_t)r * H + j] * g;
+                }
+                dxin[t * H + j] = a;
+                dh[j] = r2;
+            }
+            __syncthreads();
+        }
+        // weight gradients of this layer
+        for (int i = tid; i < 4 * H * H; i += NT) {
+            const int j = i % H, r = i / H;
+            float a = 0.f, c2 = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float g = dG[t * 4 * H + r];
+                a += g * xin[t * H + j];
+                if (t > 0) c2 += g * sv[((size_t)l * T + t - 1) * 6 * H + 5 * H + j];
+            }
+            atomicAdd(G.p[4 * l] + i, a);
+            atomicAdd(G.p[4 * l + 1] + i, c2);
+        }
+        for (int r = tid; r < 4 * H; r += NT) {
+            float a = 0.f;
+            for (int t = 0; t < T; ++t) a += dG[t * 4 * H + r];
+            atomicAdd(G.p[4 * l + 2] + r, a);
+            atomicAdd(G.p[4 * l + 3] + r, a);
+        }
+        __syncthreads();
+        if (l > 0) {
+            for (int i = tid; i < T * H; i += NT) dext[i] = dxin[i] * drop_mask(p, seed, b, l - 1, i);
+            __syncthreads();
+        } else {
+            for (int i = tid; i < T * H; i += NT) dx[(size_t)b * T * H + i] = dxin[i];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t sf_transformer_save_floats(int T, int D, int F) { return (size_t)TrSave(T, D, F).total; }
+extern "C" size_t sf_lstm_save_floats(int T, int H, int L) { return (size_t)T * L * 6 * H; }
+
+static int tr_check(const char* who, int B, int T, int D, int F, int nh) {
+    if (B <= 0 || T <= 0 || T > MAXT || D <= 0 || D % 4 != 0 || F <= 0 || F % 4 != 0 || nh <= 0 || nh > 8 || D % nh != 0) {
+        sf_set_error("%s: unsupported shape B=%d T=%d D=%d F=%d nhead=%d (T<=8, D,F multiples of 4, nhead<=8)", who, B, T, D, F, nh);
+        return SF_EINVAL;
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_transformer_layer_fwd(const float* x, float* y, const float* const* w, float* save, int B, int T,
+                                        int D, int F, int nhead, float p_drop, unsigned long long seed, void* stream) {
+    SF_REQUIRE(x && y && w, "sf_transformer_layer_fwd: null argument");
+    if (int rc = tr_check("sf_transformer_layer_fwd", B, T, D, F, nhead)) return rc;
+    SF_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "sf_transformer_layer_fwd: bad dropout %f", p_drop);
+    Ptrs12 W;
+    for (int i = 0; i < 12; ++i) { SF_REQUIRE(w[i], "sf_transformer_layer_fwd: null weight %d", i); W.p[i] = w[i]; }
+    const size_t lds = sizeof(float) * ((size_t)T * (4 * D + 3 * D + F) + 8 * T * T);
+    SF_REQUIRE(lds <= 64 * 1024, "sf_transformer_layer_fwd: sequence does not fit in LDS");
+    hipLaunchKernelGGL(transformer_fwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, x, y, W, save, T, D, F,
+                       nhead, p_drop, seed);
+    SF_LAUNCH_CHECK("sf_transformer_layer_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_transformer_layer_bwd(const float* x, const float* dy, float* dx, const float* const* w,
+                                        float* const* dw, const float* save, int B, int T, int D, int F, int nhead,
+                                        float p_drop, unsigned long long seed, void* stream) {
+    SF_REQUIRE(x && dy && dx && w && dw && save, "sf_transformer_layer_bwd: null argument");
+    if (int rc = tr_check("sf_transformer_layer_bwd", B, T, D, F, nhead)) return rc;
+    Ptrs12 W; MPtrs12 G;
+    for (int i = 0; i < 12; ++i) {
+        SF_REQUIRE(w[i] && dw[i], "sf_transformer_layer_bwd: null weight/grad %d", i);
+        W.p[i] = w[i]; G.p[i] = dw[i];
+    }
+    const size_t lds = sizeof(float) * ((size_t)T * (2 * D + F + 3 * D) + 8 * T * T);
+    SF_REQUIRE(lds <= 64 * 1024, "sf_transformer_layer_bwd: sequence does not fit in LDS");
+    hipLaunchKernelGGL(transformer_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, x, dy, dx, W, G, save, T,
+                       D, F, nhead, p_drop, seed);
+    SF_LAUNCH_CHECK("sf_transformer_layer_bwd");
+    return SF_OK;
+}
+
+extern "C" int sf_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, void* stream) {
+    SF_REQUIRE(x && pe && y && B > 0 && T > 0 && D > 0, "sf_add_pe: bad arguments");
+    const long long total = (long long)B * T * D;
+    int grid = (int)((total + NT - 1) / NT); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(add_pe_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, pe, y, total, T * D);
+    SF_LAUNCH_CHECK("sf_add_pe");
+    return SF_OK;
+}
+extern "C" int sf_mean_t_fwd(const float* x, float* y, int B, int T, int D, void* stream) {
+    SF_REQUIRE(x && y && B > 0 && T > 0 && D > 0, "sf_mean_t_fwd: bad arguments");
+    int grid = (B * D + NT - 1) / NT; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(mean_t_fwd_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, y, B, T, D);
+    SF_LAUNCH_CHECK("sf_mean_t_fwd");
+    return SF_OK;
+}
+extern "C" int sf_mean_t_bwd(const float* dy, float* dx, int B, int T, int D, void* stream) {
+    SF_REQUIRE(dy && dx && B > 0 && T > 0 && D > 0, "sf_mean_t_bwd: bad arguments");
+    int grid = (B * T * D + NT - 1) / NT; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(mean_t_bwd_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, dy, dx, B, T, D);
+    SF_LAUNCH_CHECK("sf_mean_t_bwd");
+    return SF_OK;
+}
+
+static int lstm_check(const char* who, int B, int T, int H, int L) {
+    if (B <= 0 || T <= 0 || T > MAXT || H <= 0 || H % 4 != 0 || L <= 0 || L > 4) {
+        sf_set_error("%s: unsupported shape B=%d T=%d H=%d L=%d (T<=8, H multiple of 4, L<=4)", who, B, T, H, L);
+        return SF_EINVAL;
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_lstm_fwd(const float* x, float* y, const float* const* w, float* save, int B, int T, int H, int L,
+                           float p_drop, unsigned long long seed, void* stream) {
+    SF_REQUIRE(x && y && w, "sf_lstm_fwd: null argument");
+    if (int rc = lstm_check("sf_lstm_fwd", B, T, H, L)) return rc;
+    Ptrs16 W;
+    for (int i = 0; i < 16; ++i) W.p[i] = i < 4 * L ? w[i] : nullptr;
+    for (int i = 0; i < 4 * L; ++i) SF_REQUIRE(w[i], "sf_lstm_fwd: null weight %d", i);
+    const size_t lds = sizeof(float) * ((size_t)2 * T * H + 6 * H);
+    SF_REQUIRE(lds <= 64 * 1024, "sf_lstm_fwd: sequence does not fit in LDS");
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, x, y, W, save, T, H, L, p_drop, seed);
+    SF_LAUNCH_CHECK("sf_lstm_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_lstm_bwd(const float* x, const float* dy, float* dx, const float* const* w, float* const* dw,
+                           const float* save, int B, int T, int H, int L, float p_drop, unsigned long long seed,
+                           void* stream) {
+    SF_REQUIRE(x && dy && dx && w && dw && save, "sf_lstm_bwd: null argument");
+    if (int rc = lstm_check("sf_lstm_bwd", B, T, H, L)) return rc;
+    Ptrs16 W; MPtrs16 G;
+    for (int i = 0; i < 16; ++i) { W.p[i] = i < 4 * L ? w[i] : nullptr; G.p[i] = i < 4 * L ? dw[i] : nullptr; }
+    for (int i = 0; i < 4 * L; ++i) SF_REQUIRE(w[i] && dw[i], "sf_lstm_bwd: null weight/grad %d", i);
+    const size_t lds = sizeof(float) * ((size_t)3 * T * H + (size_t)T * 4 * H + 2 * H);
+    SF_REQUIRE(lds <= 64 * 1024, "sf_lstm_bwd: sequence does not fit in LDS");
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, x, dy, dx, W, G, save, T, H, L,
+                       p_drop, seed);
+    SF_LAUNCH_CHECK("sf_lstm_bwd");
+    return SF_OK;
+}

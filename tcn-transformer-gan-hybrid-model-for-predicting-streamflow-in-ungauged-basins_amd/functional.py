@@ -1,0 +1,465 @@
+"""torch.autograd Functions that chain the HIP kernels of one module (forward and backward).
+
+Tensors crossing a module boundary are plain f32 NCHW torch tensors, exactly as in the
+reference; inside a Function activations are NHWC in the compute dtype (f32 or bf16) with
+channel counts padded to a multiple of 8.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+_FORCED_DTYPE: Optional[torch.dtype] = None
+
+
+def set_compute_dtype(dtype: Optional[torch.dtype]):
+    """Force the kernels' compute dtype (torch.float32 / torch.bfloat16); None = follow autocast."""
+    global _FORCED_DTYPE
+    if dtype not in (None, torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32, bfloat16 or None")
+    _FORCED_DTYPE = dtype
+
+
+def compute_dtype() -> torch.dtype:
+    """bf16 inside torch.autocast('cuda') (the reference's AMP switch, src/train.py:192), else f32."""
+    if _FORCED_DTYPE is not None:
+        return _FORCED_DTYPE
+    return torch.bfloat16 if torch.is_autocast_enabled("cuda") else torch.float32
+
+
+def new_seed() -> int:
+    """A dropout seed drawn from torch's CPU generator (honours torch.manual_seed, no GPU sync)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
+
+
+def _taps3():
+    return [(r - 1, s - 1) for r in range(3) for s in range(3)]
+
+
+def _taps3_dgrad():
+    return [(1 - r, 1 - s) for r in range(3) for s in range(3)]
+
+
+def conv3x3_geom(N, H, W, C, dgrad=False):
+    return ops.conv_geom(N, H, W, C, H, W, 1, 1, H, W, _taps3_dgrad() if dgrad else _taps3(),
+                         tap_rs=list(range(9)))
+
+
+def conv3x3_wgeom(N, H, W, C, cin_real):
+    return ops.conv_geom(N, H, W, C, H, W, 1, 1, H, W, _taps3(), tap_rs=list(range(9)), cin_real=cin_real, RS=9)
+
+
+# ------------------------------------------------------------------------------ encoder
+class EncoderFn(torch.autograd.Function):
+    """CNNEncoder.forward (src/model/cnn_encoder.py:71-93): per layer conv3x3 -> BatchNorm ->
+    ReLU -> maxpool2 (all but last) ; adaptive average pool to 32x32 after the last layer."""
+
+    @staticmethod
+    def forward(ctx, x, training, cdtype, target, *params):
+        L = len(params) // 5
+        N, Cin, H, W = x.shape
+        e = ops.epc(ops.code_of(cdtype))
+        a = ops.nchw_to_nhwc(x.contiguous(), cdtype, ops.roundup(Cin, e))
+        saved = []
+        h, w = H, W
+        out = None
+        for l in range(L):
+            wt, gamma, beta, rm, rv = params[5 * l: 5 * l + 5]
+            K = wt.shape[0]
+            Kpad = ops.roundup(K, 8)
+            C = a.shape[-1]
+            wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), False, Kpad, C)
+            z = torch.empty((N, h, w, Kpad), device=x.device, dtype=cdtype)
+            ops.conv_fprop(a, wp, z, conv3x3_geom(N, h, w, C), Kpad)
+            M = N * h * w
+            ws = None
+            if training:
+                ws = torch.empty(2 * Kpad, device=x.device, dtype=torch.float64)
+                ops.bn_stats(z, M, Kpad, ws)
+            st = ops.bn_finalize(ws, M, Kpad, K, gamma.detach(), beta.detach(), rm, rv, training)
+            saved.append((a, z, st, (h, w)))
+            if l < L - 1:
+                a = ops.bn_relu_maxpool_fwd(z, st)
+                h, w = h // 2, w // 2
+            else:
+                oh, ow = (target, target) if (h != target or w != target) else (h, w)
+                out = ops.bn_relu_avgpool_fwd(z, st, K, oh, ow, torch.float32)
+        ctx.saved = saved
+        ctx.params = params
+        ctx.training = training
+        ctx.cdtype = cdtype
+        ctx.in_shape = (N, Cin, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params, cdtype, training = ctx.params, ctx.cdtype, ctx.training
+        L = len(params) // 5
+        N, Cin, H, W = ctx.in_shape
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        K_last = params[5 * (L - 1)].shape[0]
+        dy = ops.nchw_to_nhwc(dout.contiguous().float(), cdtype, ops.roundup(K_last, 8))
+        oh, ow = dout.shape[-2], dout.shape[-1]
+        dx = None
+        for l in range(L - 1, -1, -1):
+            wt, gamma = params[5 * l], params[5 * l + 1]
+            a, z, st, (h, w) = ctx.saved[l]
+            K, Kpad, C = wt.shape[0], z.shape[-1], a.shape[-1]
+            cin_real = wt.shape[1]
+            mode = 1 if l == L - 1 else 0
+            dz, dgamma, dbeta = ops.bn_backward(mode, z, dy, st, gamma.detach(), K, training, oh, ow)
+            dw = torch.zeros_like(wt)
+            ops.conv_wgrad(a, dz, dw, conv3x3_wgeom(N, h, w, C, cin_real), Kpad)
+            grads[5 * l], grads[5 * l + 1], grads[5 * l + 2] = dw, dgamma, dbeta
+            if l > 0 or ctx.needs_input_grad[0]:
+                wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), True, C, Kpad)
+                da = torch.empty((N, h, w, C), device=dz.device, dtype=cdtype)
+                ops.conv_fprop(dz, wT, da, conv3x3_geom(N, h, w, Kpad, dgrad=True), C)
+                if l > 0:
+                    dy = da
+                else:
+                    dx = ops.nhwc_to_nchw(da, Cin)
+        ctx.saved = None
+        return (dx, None, None, None, *grads)
+
+
+# ------------------------------------------------------------------------------ 262144-wide Linear
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b for the two skinny, weight-bandwidth-bound Linear layers
+    (src/model/transformer_module.py:73 / src/model/lstm_module.py:36, src/model/__init__.py:92-95)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, cdtype):
+        M, K = x.shape
+        Nf = W.shape[0]
+        if K % 8 or Nf % 8:
+            raise NotImplementedError(f"Linear {K}->{Nf}: both sizes must be multiples of 8 on the HIP path")
+        xt = ops.cast(x.contiguous().float(), cdtype)
+        Wt = ops.cast(W.detach().contiguous(), cdtype)
+        bk = 32 if cdtype == torch.bfloat16 else 16
+        nsplit = max(1, min(256, K // (bk * 16)))
+        y = (torch.zeros if nsplit > 1 else torch.empty)((M, Nf), device=x.device, dtype=torch.float32)
+        ops.linear_gemm(Wt, xt, y, Nf, M, K, K, K, Nf, False, False, ops.OUT_JI, nsplit,
+                        b.detach().contiguous() if b is not None else None)
+        ctx.save_for_backward(xt, Wt)
+        ctx.dims = (M, K, Nf, bk)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xt, Wt = ctx.saved_tensors
+        M, K, Nf, bk = ctx.dims
+        dy = dy.contiguous().float()
+        dyt = ops.cast(dy, xt.dtype)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            nsplit = max(1, min(256, Nf // (bk * 16)))
+            dx = (torch.zeros if nsplit > 1 else torch.empty)((M, K), device=dy.device, dtype=torch.float32)
+            ops.linear_gemm(Wt, dyt, dx, K, M, Nf, K, Nf, K, True, False, ops.OUT_JI, nsplit)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty((Nf, K), device=dy.device, dtype=torch.float32)
+            ops.linear_gemm(dyt, xt, dW, Nf, K, M, Nf, K, K, True, True, ops.OUT_IJ, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum_f32(dy)
+        return dx, dW, db, None
+
+
+# ------------------------------------------------------------------------------ temporal modules
+class TransformerStackFn(torch.autograd.Function):
+    """+positional encoding, num_layers post-LN encoder layers, mean over time
+    (src/model/transformer_module.py:112-118)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, nhead, p_drop, seed, *ws):
+        L = len(ws) // 12
+        B, T, D = x.shape
+        Fd = ws[4].shape[0]
+        wsd = [w.detach().contiguous() for w in ws]
+        h = ops.add_pe(x.contiguous().float(), pe[:T].contiguous())
+        need_save = any(ctx.needs_input_grad)
+        inputs, saves = [], []
+        nsave = ops.transformer_save_floats(T, D, Fd)
+        for l in range(L):
+            save = torch.empty(B * nsave, device=x.device, dtype=torch.float32) if need_save else None
+            y = ops.transformer_layer_fwd(h, wsd[12 * l: 12 * l + 12], nhead, p_drop, seed + 7919 * l, save)
+            inputs.append(h)
+            saves.append(save)
+            h = y
+        out = ops.mean_t_fwd(h)
+        ctx.inputs, ctx.saves, ctx.ws = inputs, saves, wsd
+        ctx.cfg = (nhead, p_drop, seed, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        nhead, p_drop, seed, T = ctx.cfg
+        L = len(ctx.ws) // 12
+        g = ops.mean_t_bwd(dout.contiguous().float(), T)
+        dws = [torch.zeros_like(w) for w in ctx.ws]
+        for l in range(L - 1, -1, -1):
+            g = ops.transformer_layer_bwd(ctx.inputs[l], g, ctx.ws[12 * l: 12 * l + 12], dws[12 * l: 12 * l + 12],
+                                          ctx.saves[l], nhead, p_drop, seed + 7919 * l)
+        ctx.inputs = ctx.saves = None
+        return (g, None, None, None, None, *dws)
+
+
+class LstmFn(torch.autograd.Function):
+    """nn.LSTM(H, H, L, batch_first) -> h_n[-1] (src/model/lstm_module.py:66-75)."""
+
+    @staticmethod
+    def forward(ctx, x, L, p_drop, seed, *ws):
+        B, T, H = x.shape
+        wsd = [w.detach().contiguous() for w in ws]
+        x = x.contiguous().float()
+        need_save = any(ctx.needs_input_grad)
+        save = torch.empty(B * ops.lstm_save_floats(T, H, L), device=x.device, dtype=torch.float32) if need_save else None
+        y = ops.lstm_fwd(x, wsd, L, p_drop, seed, save)
+        ctx.x, ctx.save, ctx.ws, ctx.cfg = x, save, wsd, (L, p_drop, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L, p_drop, seed = ctx.cfg
+        dws = [torch.zeros_like(w) for w in ctx.ws]
+        dx = ops.lstm_bwd(ctx.x, dy.contiguous().float(), ctx.ws, dws, ctx.save, L, p_drop, seed)
+        ctx.x = ctx.save = None
+        return (dx, None, None, None, *dws)
+
+
+# ------------------------------------------------------------------------------ decoder
+class DecoderFn(torch.autograd.Function):
+    """SimpleUpsamplingDecoder.forward (src/model/decoder.py:154-177)."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW, cdtype, w1, b1, w2, b2, w3, b3):
+        B, C, h, w = x.shape
+        if C % 8:
+            raise NotImplementedError("decoder input channels must be a multiple of 8 on the HIP path")
+        Hc = w1.shape[0]
+        Hp = ops.roundup(Hc, 8)
+        src = ops.nchw_to_nhwc(x.contiguous().float(), torch.float32, C)
+        up = ops.bilinear_fwd(src, OH, OW, cdtype)
+        w1p = ops.pack_conv_weight(w1.detach().contiguous(), cdtype, list(range(9)), False, Hp, C)
+        w2p = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), False, Hp, Hp)
+        bp1 = _pad_vec(b1.detach(), Hp)
+        bp2 = _pad_vec(b2.detach(), Hp)
+        h1 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
+        ops.conv_fprop(up, w1p, h1, conv3x3_geom(B, OH, OW, C), Hp, bias=bp1, act=ops.ACT_RELU)
+        h2 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
+        ops.conv_fprop(h1, w2p, h2, conv3x3_geom(B, OH, OW, Hp), Hp, bias=bp2, act=ops.ACT_RELU)
+        w3c = w3.detach().contiguous()
+        y = ops.conv_k1_fwd(h2, w3c, b3.detach().contiguous(), 1, 0)
+        ctx.save_for_backward(up, h1, h2, w3c)
+        ctx.weights = (w1, w2)
+        ctx.dims = (B, C, h, w, OH, OW, Hc, Hp, cdtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        up, h1, h2, w3c = ctx.saved_tensors
+        w1, w2 = ctx.weights
+        B, C, h, w, OH, OW, Hc, Hp, cdtype = ctx.dims
+        dy = dy.contiguous().float()
+        dw3, db3 = ops.conv_k1_bwd_weight(h2, dy, Hc, 1, 0)
+        dz2 = ops.conv_k1_bwd_data(dy, w3c, h2, 1, 0, relu_mask=True)
+        dw2 = torch.zeros_like(w2)
+        ops.conv_wgrad(h1, dz2, dw2, conv3x3_wgeom(B, OH, OW, Hp, Hc), Hp)
+        db2 = ops.channel_sum(dz2, Hc)
+        w2T = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), True, Hp, Hp)
+        dz1 = torch.empty_like(h1)
+        ops.conv_fprop(dz2, w2T, dz1, conv3x3_geom(B, OH, OW, Hp, dgrad=True), Hp, aux=h1, aux_mode=1)
+        dw1 = torch.zeros_like(w1)
+        ops.conv_wgrad(up, dz1, dw1, conv3x3_wgeom(B, OH, OW, C, C), Hp)
+        db1 = ops.channel_sum(dz1, Hc)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w1T = ops.pack_conv_weight(w1.detach().contiguous(), cdtype, list(range(9)), True, C, Hp)
+            dup = torch.empty_like(up)
+            ops.conv_fprop(dz1, w1T, dup, conv3x3_geom(B, OH, OW, Hp, dgrad=True), C)
+            dsrc = ops.bilinear_bwd(dup, h, w)
+            dx = ops.nhwc_to_nchw(dsrc, C)
+        return dx, None, None, None, dw1, db1, dw2, db2, dw3, db3
+
+
+def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
+    v = v.contiguous().float()
+    if v.numel() == n:
+        return v
+    out = torch.zeros(n, device=v.device, dtype=torch.float32)
+    out[: v.numel()] = v
+    return out
+
+
+# ------------------------------------------------------------------------------ discriminator
+def _s2_geom(N, IH, IW, C, OH, OW):
+    taps = [(r - 1, s - 1) for r in range(4) for s in range(4)]
+    return ops.conv_geom(N, IH, IW, C, OH, OW, 2, 2, OH, OW, taps, tap_rs=list(range(16)))
+
+
+def _s2_wgeom(N, IH, IW, C, OH, OW, cin_real):
+    taps = [(r - 1, s - 1) for r in range(4) for s in range(4)]
+    return ops.conv_geom(N, IH, IW, C, OH, OW, 2, 2, OH, OW, taps, tap_rs=list(range(16)), cin_real=cin_real, RS=16)
+
+
+def _s2_dgrad_classes(IH, IW):
+    """Transposed 4x4 stride-2 pad-1 conv as four stride-1 2x2 convs, one per output parity."""
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            rows = [(r, (py + 1 - r) // 2) for r in range(4) if (py + 1 - r) % 2 == 0]
+            cols = [(s, (px + 1 - s) // 2) for s in range(4) if (px + 1 - s) % 2 == 0]
+            taps = [(dy, dx) for (_, dy) in rows for (_, dx) in cols]
+            rs = [r * 4 + s for (r, _) in rows for (s, _) in cols]
+            mh, mw = (IH - py + 1) // 2, (IW - px + 1) // 2
+            if mh > 0 and mw > 0:
+                out.append((py, px, taps, rs, mh, mw))
+    return out
+
+
+class DiscriminatorFn(torch.autograd.Function):
+    """PatchDiscriminator.forward (src/model/gan.py:36-64); BatchNorm always uses batch
+    statistics and updates its running buffers, as the reference never puts D in eval mode."""
+
+    @staticmethod
+    def forward(ctx, x, cdtype, training, w1, b1, *rest):
+        # rest = 3 x (w, b, gamma, beta, rm, rv) + (w5, b5)
+        N, _, H, W = x.shape
+        x = x.contiguous().float()
+        w1c, b1c = w1.detach().contiguous(), b1.detach().contiguous()
+        K1 = w1.shape[0]
+        if K1 % 8:
+            raise NotImplementedError("discriminator width must be a multiple of 8 on the HIP path")
+        y = ops.dconv1_fwd(x, w1c, b1c, cdtype)
+        acts = [y]
+        zs, sts = [], []
+        for i in range(3):
+            wt, b, gamma, beta, rm, rv = rest[6 * i: 6 * i + 6]
+            K, C = wt.shape[0], y.shape[-1]
+            ih, iw = y.shape[1], y.shape[2]
+            oh, ow = (ih - 2) // 2 + 1, (iw - 2) // 2 + 1
+            if oh < 1 or ow < 1:
+                raise ValueError("input too small for the PatchGAN discriminator")
+            wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(16)), False, K, C)
+            z = torch.empty((N, oh, ow, K), device=x.device, dtype=cdtype)
+            ops.conv_fprop(y, wp, z, _s2_geom(N, ih, iw, C, oh, ow), K, bias=b.detach().contiguous())
+            M = N * oh * ow
+            ws = torch.empty(2 * K, device=x.device, dtype=torch.float64)
+            ops.bn_stats(z, M, K, ws)
+            st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, True)
+            y = ops.bn_lrelu_fwd(z, st)
+            zs.append(z)
+            sts.append(st)
+            acts.append(y)
+        w5, b5 = rest[18], rest[19]
+        w5c = w5.detach().contiguous()
+        out = ops.conv_k1_fwd(y, w5c, b5.detach().contiguous(), 4, 1)
+        ctx.x, ctx.acts, ctx.zs, ctx.sts = x, acts, zs, sts
+        ctx.params = (w1, b1, *rest)
+        ctx.cdtype = cdtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, acts, zs, sts, cdtype = ctx.x, ctx.acts, ctx.zs, ctx.sts, ctx.cdtype
+        w1, b1, *rest = ctx.params
+        N = x.shape[0]
+        dout = dout.contiguous().float()
+        w5 = rest[18]
+        grads: List[Optional[torch.Tensor]] = [None] * (2 + len(rest))
+        y4 = acts[3]
+        dw5, db5 = ops.conv_k1_bwd_weight(y4, dout, w5.shape[1], 4, 1)
+        grads[2 + 18], grads[2 + 19] = dw5, db5
+        dy = ops.conv_k1_bwd_data(dout, w5.detach().contiguous(), y4, 4, 1, relu_mask=False)
+        for i in (2, 1, 0):
+            wt, b, gamma = rest[6 * i], rest[6 * i + 1], rest[6 * i + 2]
+            z, st, yin = zs[i], sts[i], acts[i]
+            K, C = wt.shape[0], yin.shape[-1]
+            ih, iw, oh, ow = yin.shape[1], yin.shape[2], z.shape[1], z.shape[2]
+            dz, dgamma, dbeta = ops.bn_backward(2, z, dy, st, gamma.detach(), K, True)
+            dw = torch.zeros_like(wt)
+            ops.conv_wgrad(yin, dz, dw, _s2_wgeom(N, ih, iw, C, oh, ow, C), K)
+            db = ops.channel_sum(dz, K)
+            grads[2 + 6 * i], grads[2 + 6 * i + 1] = dw, db
+            grads[2 + 6 * i + 2], grads[2 + 6 * i + 3] = dgamma, dbeta
+            # data gradient: four parity classes of the transposed stride-2 conv
+            dyin = torch.empty_like(yin)
+            for (py, px, taps, rs, mh, mw) in _s2_dgrad_classes(ih, iw):
+                wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, rs, True, C, K)
+                geom = ops.conv_geom(N, oh, ow, K, mh, mw, 1, 1, ih, iw, taps, osh=2, osw=2, ooy=py, oox=px)
+                if i == 0:  # layer below has no BatchNorm: fold its LeakyReLU derivative in
+                    ops.conv_fprop(dz, wT, dyin, geom, C, aux=yin, aux_mode=2)
+                else:
+                    ops.conv_fprop(dz, wT, dyin, geom, C)
+            dy = dyin
+        dw1, db1 = ops.dconv1_bwd_weight(x, dy)
+        grads[0], grads[1] = dw1, db1
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.dconv1_bwd_data(dy, w1.detach().contiguous(), x.shape[2], x.shape[3])
+        ctx.x = ctx.acts = ctx.zs = ctx.sts = None
+        return (dx, None, None, *grads)
+
+
+# ------------------------------------------------------------------------------ losses
+def pack_stations(positions: Sequence[torch.Tensor], runoffs: Sequence[torch.Tensor], device):
+    """List-of-tensors station batch (src/train.py:181-188) -> packed device arrays with ONE
+    host-to-device copy: int32 [S,2] positions, f32 [S] runoffs, int32 [B+1] offsets."""
+    B = len(positions)
+    counts = [int(r.numel()) for r in runoffs]
+    S = sum(counts)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    buf = torch.zeros(max(S, 1) * 3 + B + 1, dtype=torch.int32)
+    if S:
+        pos = torch.cat([p.reshape(-1, 2).to(torch.int32).cpu() for p, c in zip(positions, counts) if c], dim=0)
+        run = torch.cat([r.reshape(-1).to(torch.float32).cpu() for r, c in zip(runoffs, counts) if c], dim=0)
+        buf[: 2 * S] = pos.reshape(-1)
+        buf[2 * S: 3 * S] = run.view(torch.int32)
+    buf[3 * max(S, 1):] = torch.tensor(offs, dtype=torch.int32)
+    d = buf.to(device, non_blocking=True)
+    n = max(S, 1)
+    return d[: 2 * n].view(-1, 2), d[2 * n: 3 * n].view(torch.float32), d[3 * n:], S
+
+
+class ImageStationLossFn(torch.autograd.Function):
+    """ImageLoss + StationLoss + their weighted sum (src/loss.py:47-70,116-160,227-230), forward
+    and backward in one launch sequence.  Returns a [3] tensor: total, image, station; only
+    `total` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, pred, target, pos, runoff, offsets, S, cfg):
+        (image_metric, nonzero_weight, zero_threshold, ksize, station_metric, iw, sw) = cfg
+        losses, dpred = ops.image_station_loss(pred.contiguous().float(), target.contiguous().float(), pos, runoff,
+                                               offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
+                                               station_metric, iw, sw)
+        ctx.save_for_backward(dpred)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g[0], None, None, None, None, None, None
+
+
+class BceLogitsFn(torch.autograd.Function):
+    """nn.BCEWithLogitsLoss() (mean) against a constant or a tensor label (src/model/gan.py:82)."""
+
+    @staticmethod
+    def forward(ctx, x, label, labels):
+        loss, dx = ops.bce_logits(x.contiguous().float(), float(label),
+                                  labels.contiguous().float() if labels is not None else None,
+                                  need_grad=ctx.needs_input_grad[0])
+        ctx.dx = dx
+        ctx.shape = x.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dx = ctx.dx
+        ctx.dx = None
+        return (dx * g).reshape(ctx.shape), None, None

@@ -1,0 +1,397 @@
+"""nn.Module surfaces of the reference's hot path, backed by the HIP kernels.
+
+Constructor signatures, attribute names and state_dict keys / shapes follow the reference
+modules (cited per class) so that its configs, checkpoints and drivers keep working; the
+standard torch.nn layers created here are only parameter containers (they are never called),
+the arithmetic runs in functional.py's autograd Functions.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import functional as SF
+from . import ops
+
+
+def _need_cuda(t: torch.Tensor, who: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: this implementation only runs on an MI355X GPU (got a {t.device} tensor); "
+                           "there is no CPU path")
+
+
+# ------------------------------------------------------------------------------ encoder
+class CNNEncoder(nn.Module):
+    """Mirror of src/model/cnn_encoder.py:8-97."""
+
+    def __init__(self, input_channels: int, hidden_dim: int, num_layers: int = 2, kernel_size: int = 3,
+                 padding: int = 1, use_batchnorm: bool = True):
+        super().__init__()
+        if kernel_size != 3 or padding != 1 or not use_batchnorm:
+            raise NotImplementedError("the HIP encoder implements the reference's configuration only: "
+                                      "3x3 convolutions, padding 1, BatchNorm")
+        self.input_channels = input_channels
+        self.hidden_dim = hidden_dim
+        self.num_layers = num_layers
+        self.target_spatial = 32
+        layers: List[nn.Module] = []
+        in_ch = input_channels
+        for i in range(num_layers):
+            out_ch = hidden_dim * (2 ** i)
+            layers.append(nn.Conv2d(in_ch, out_ch, kernel_size=3, padding=1, bias=False))
+            layers.append(nn.BatchNorm2d(out_ch))
+            layers.append(nn.ReLU(inplace=True))
+            if i < num_layers - 1:
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            in_ch = out_ch
+        self.encoder = nn.Sequential(*layers)
+        self.out_channels = in_ch
+        self.adaptive_pool = nn.AdaptiveAvgPool2d((self.target_spatial, self.target_spatial))
+
+    def _layer_params(self):
+        ps = []
+        mods = list(self.encoder)
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.Conv2d):
+                bn = mods[i + 1]
+                ps += [m.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        return ps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 5:
+            B, T, C, H, W = x.shape
+            x = x.reshape(B * T, C, H, W)
+        _need_cuda(x, "CNNEncoder")
+        if self.training:
+            for m in self.encoder:
+                if isinstance(m, nn.BatchNorm2d):
+                    m.num_batches_tracked += 1
+        return SF.EncoderFn.apply(x.float(), self.training, SF.compute_dtype(), self.target_spatial,
+                                  *self._layer_params())
+
+    def get_output_channels(self) -> int:
+        return self.out_channels
+
+
+# ------------------------------------------------------------------------------ temporal modules
+class PositionalEncoding(nn.Module):
+    """Mirror of src/model/transformer_module.py:8-38 (buffer `pe` [1, max_len, d_model])."""
+
+    def __init__(self, d_model: int, max_len: int = 5000):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        if d_model % 2 == 1:
+            pe[:, 1::2] = torch.cos(position * div_term[:-1])
+        else:
+            pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _need_cuda(x, "PositionalEncoding")
+        return ops.add_pe(x.contiguous().float(), self.pe[0, : x.size(1)].contiguous())
+
+
+_LAYER_KEYS = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+               "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+               "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+def _get_attr(m: nn.Module, dotted: str):
+    for part in dotted.split("."):
+        m = getattr(m, part)
+    return m
+
+
+class TransformerModule(nn.Module):
+    """Mirror of src/model/transformer_module.py:41-124."""
+
+    def __init__(self, input_dim: int, hidden_dim: int, num_layers: int = 2, num_heads: int = 4,
+                 dropout: float = 0.2, feedforward_dim: Optional[int] = None):
+        super().__init__()
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        if feedforward_dim is None:
+            feedforward_dim = hidden_dim * 4
+        self.input_proj = nn.Linear(input_dim, hidden_dim) if input_dim != hidden_dim else None
+        self.pos_encoder = PositionalEncoding(hidden_dim, max_len=100)
+        layer = nn.TransformerEncoderLayer(d_model=hidden_dim, nhead=num_heads, dim_feedforward=feedforward_dim,
+                                           dropout=dropout, batch_first=True, activation="relu")
+        self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=num_layers)
+        self.num_heads, self.dropout, self.num_layers = num_heads, dropout, num_layers
+        self.output_dim = hidden_dim
+
+    def _layer_weights(self):
+        ws = []
+        for l in self.transformer_encoder.layers:
+            ws += [_get_attr(l, k) for k in _LAYER_KEYS]
+        return ws
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _need_cuda(x, "TransformerModule")
+        B, T, _ = x.shape
+        if self.input_proj is not None:
+            x = SF.LinearFn.apply(x.reshape(B * T, -1), self.input_proj.weight, self.input_proj.bias,
+                                  SF.compute_dtype()).view(B, T, -1)
+        p = self.dropout if self.training else 0.0
+        seed = SF.new_seed() if p > 0 else 0
+        return SF.TransformerStackFn.apply(x, self.pos_encoder.pe[0], self.num_heads, p, seed,
+                                           *self._layer_weights())
+
+    def get_output_dim(self) -> int:
+        return self.output_dim
+
+
+class LSTMModule(nn.Module):
+    """Mirror of src/model/lstm_module.py:7-81 (unidirectional path; the reference model never
+    enables bidirectional, src/model/__init__.py:82-87)."""
+
+    def __init__(self, input_dim: int, hidden_dim: int, num_layers: int = 1, dropout: float = 0.2,
+                 bidirectional: bool = False):
+        super().__init__()
+        if bidirectional:
+            raise NotImplementedError("bidirectional LSTM is not on the reference's hot path and is not built")
+        self.input_dim, self.hidden_dim, self.num_layers, self.bidirectional = input_dim, hidden_dim, num_layers, False
+        self.input_proj = nn.Linear(input_dim, hidden_dim) if input_dim != hidden_dim else None
+        self.lstm = nn.LSTM(input_size=hidden_dim, hidden_size=hidden_dim, num_layers=num_layers,
+                            dropout=dropout if num_layers > 1 else 0, bidirectional=False, batch_first=True)
+        self.dropout = dropout if num_layers > 1 else 0.0
+        self.output_dim = hidden_dim
+
+    def _weights(self):
+        ws = []
+        for l in range(self.num_layers):
+            ws += [getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}"),
+                   getattr(self.lstm, f"bias_ih_l{l}"), getattr(self.lstm, f"bias_hh_l{l}")]
+        return ws
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _need_cuda(x, "LSTMModule")
+        B, T, _ = x.shape
+        if self.input_proj is not None:
+            x = SF.LinearFn.apply(x.reshape(B * T, -1), self.input_proj.weight, self.input_proj.bias,
+                                  SF.compute_dtype()).view(B, T, -1)
+        p = self.dropout if self.training else 0.0
+        seed = SF.new_seed() if p > 0 else 0
+        return SF.LstmFn.apply(x, self.num_layers, p, seed, *self._weights())
+
+    def get_output_dim(self) -> int:
+        return self.output_dim
+
+
+# ------------------------------------------------------------------------------ decoder
+class SimpleUpsamplingDecoder(nn.Module):
+    """Mirror of src/model/decoder.py:125-177."""
+
+    def __init__(self, input_channels: int, output_height: int, output_width: int, hidden_channels: int = 64):
+        super().__init__()
+        self.output_height, self.output_width = output_height, output_width
+        self.conv1 = nn.Conv2d(input_channels, hidden_channels, kernel_size=3, padding=1)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(hidden_channels, hidden_channels, kernel_size=3, padding=1)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.output_conv = nn.Conv2d(hidden_channels, 1, kernel_size=1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _need_cuda(x, "SimpleUpsamplingDecoder")
+        return SF.DecoderFn.apply(x.float(), self.output_height, self.output_width, SF.compute_dtype(),
+                                  self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                  self.output_conv.weight, self.output_conv.bias)
+
+
+# ------------------------------------------------------------------------------ generator
+class StreamflowPredictionModel(nn.Module):
+    """Mirror of src/model/__init__.py:13-151."""
+
+    def __init__(self, config: Dict):
+        super().__init__()
+        self.config = config
+        model_cfg = config.get("model", {})
+        data_cfg = config.get("data", {})
+        self.input_channels = model_cfg.get("input_channels", 10)
+        self.hidden_dim = model_cfg.get("hidden_dim", 128)
+        self.num_layers = model_cfg.get("num_layers", 2)
+        self.backbone = model_cfg.get("backbone", "CNN")
+        self.temporal_module_type = model_cfg.get("temporal_module", "LSTM")
+        self.upscale_factor = data_cfg.get("upscale_factor", 2)
+        self.window_size = data_cfg.get("window_size", 5)
+        img_size = data_cfg.get("image_size", [128, 128])
+        if isinstance(img_size, int):
+            self.input_height = self.input_width = int(img_size)
+        else:
+            self.input_height, self.input_width = int(img_size[0]), int(img_size[1])
+        self.output_height = self.input_height * self.upscale_factor
+        self.output_width = self.input_width * self.upscale_factor
+        if self.hidden_dim % 8:
+            raise NotImplementedError("hidden_dim must be a multiple of 8 on the HIP path")
+        self.cnn_encoder = CNNEncoder(self.input_channels, self.hidden_dim, self.num_layers, 3, 1, True)
+        cnn_out = self.cnn_encoder.get_output_channels()
+        enc_h = enc_w = self.cnn_encoder.target_spatial
+        feat = cnn_out * enc_h * enc_w
+        if self.temporal_module_type.upper() == "TRANSFORMER":
+            self.temporal_module = TransformerModule(feat, self.hidden_dim, self.num_layers, num_heads=4, dropout=0.2)
+        else:
+            self.temporal_module = LSTMModule(feat, self.hidden_dim, self.num_layers, dropout=0.2)
+        self.temporal_to_spatial = nn.Linear(self.temporal_module.get_output_dim(), feat)
+        self.encoded_h, self.encoded_w, self.cnn_out_channels = enc_h, enc_w, cnn_out
+        self.decoder = SimpleUpsamplingDecoder(cnn_out, self.output_height, self.output_width, hidden_channels=64)
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        _need_cuda(images, "StreamflowPredictionModel")
+        B, T, C, H, W = images.shape
+        encoded = self.cnn_encoder(images.reshape(B * T, C, H, W))
+        _, oc, he, we = encoded.shape
+        t_out = self.temporal_module(encoded.reshape(B, T, -1))
+        sp = SF.LinearFn.apply(t_out, self.temporal_to_spatial.weight, self.temporal_to_spatial.bias,
+                               SF.compute_dtype())
+        return self.decoder(sp.view(B, oc, he, we))
+
+    def get_num_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+
+# ------------------------------------------------------------------------------ GAN
+class PatchDiscriminator(nn.Module):
+    """Mirror of src/model/gan.py:7-64."""
+
+    def __init__(self, input_channels: int = 1, hidden_channels: int = 64):
+        super().__init__()
+        if input_channels != 1:
+            raise NotImplementedError("the HIP discriminator takes the single-channel flow map of the reference")
+
+        def conv_block(i, o):
+            return nn.Sequential(nn.Conv2d(i, o, kernel_size=4, stride=2, padding=1), nn.BatchNorm2d(o),
+                                 nn.LeakyReLU(0.2, inplace=True))
+
+        hc = hidden_channels
+        self.model = nn.Sequential(
+            nn.Conv2d(input_channels, hc, kernel_size=4, stride=2, padding=1),
+            nn.LeakyReLU(0.2, inplace=True),
+            conv_block(hc, hc * 2), conv_block(hc * 2, hc * 4), conv_block(hc * 4, hc * 8),
+            nn.Conv2d(hc * 8, 1, kernel_size=4, stride=1, padding=1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _need_cuda(x, "PatchDiscriminator")
+        m = self.model
+        ps = [m[0].weight, m[0].bias]
+        for i in (2, 3, 4):
+            conv, bn = m[i][0], m[i][1]
+            ps += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+            bn.num_batches_tracked += 1
+        ps += [m[5].weight, m[5].bias]
+        return SF.DiscriminatorFn.apply(x.float(), SF.compute_dtype(), True, *ps)
+
+
+class _BceWithLogits(nn.Module):
+    """nn.BCEWithLogitsLoss() replacement: mean reduction, tensor labels."""
+
+    def forward(self, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        _need_cuda(logits, "GANLoss.gan_loss")
+        return SF.BceLogitsFn.apply(logits, 0.0, labels.to(logits.device).expand_as(logits))
+
+
+class _L1(nn.Module):
+    def forward(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        # ImageLoss with nonzero_weight 1 and metric MAE is exactly mean |a - b|
+        return ImageLoss(metric="MAE", nonzero_weight=1.0)(a, b)
+
+
+class GANLoss(nn.Module):
+    """Mirror of src/model/gan.py:67-132."""
+
+    def __init__(self, lambda_gan: float = 1.0, lambda_pixel: float = 1.0):
+        super().__init__()
+        self.lambda_gan, self.lambda_pixel = lambda_gan, lambda_pixel
+        self.gan_loss = _BceWithLogits()
+        self.pixel_loss = _L1()
+
+    def discriminator_loss(self, disc_real: torch.Tensor, disc_fake: torch.Tensor) -> torch.Tensor:
+        _need_cuda(disc_real, "GANLoss.discriminator_loss")
+        loss_real = SF.BceLogitsFn.apply(disc_real, 0.9, None)  # label smoothing, src/model/gan.py:102
+        loss_fake = SF.BceLogitsFn.apply(disc_fake, 0.0, None)
+        return (loss_real + loss_fake) / 2
+
+    def generator_loss(self, disc_fake, generated, target):
+        loss_gan = SF.BceLogitsFn.apply(disc_fake, 1.0, None)
+        return self.lambda_gan * loss_gan + self.lambda_pixel * self.pixel_loss(generated, target)
+
+
+# ------------------------------------------------------------------------------ losses
+_METRIC = {"MSE": 0, "MAE": 1}
+
+
+class ImageLoss(nn.Module):
+    """Mirror of src/loss.py:9-70."""
+
+    def __init__(self, metric: str = "MSE", upscale_factor: int = 2, nonzero_weight: float = 10.0,
+                 zero_threshold: float = 1e-6):
+        super().__init__()
+        self.metric = metric.upper()
+        self.upscale_factor, self.nonzero_weight, self.zero_threshold = upscale_factor, nonzero_weight, zero_threshold
+        if self.metric not in _METRIC:
+            raise ValueError(f"Unknown metric: {metric}")
+
+    def forward(self, predictions: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        _need_cuda(predictions, "ImageLoss")
+        pos, run, offs, S = _no_stations(predictions)
+        cfg = (_METRIC[self.metric], float(self.nonzero_weight), float(self.zero_threshold), 1, 0, 1.0, 0.0)
+        return SF.ImageStationLossFn.apply(predictions, targets.to(predictions.device), pos, run, offs, 0, cfg)[0]
+
+
+def _no_stations(pred: torch.Tensor):
+    B = pred.shape[0]
+    z = torch.zeros(3 + B + 1, device=pred.device, dtype=torch.int32)
+    return z[:2].view(-1, 2), z[2:3].view(torch.float32), z[3:], 0
+
+
+class StationLoss(nn.Module):
+    """Mirror of src/loss.py:73-160."""
+
+    def __init__(self, kernel_size: int = 3, metric: str = "MSE"):
+        super().__init__()
+        self.kernel_size, self.metric = kernel_size, metric.upper()
+        if self.metric not in _METRIC:
+            raise ValueError(f"Unknown metric: {metric}")
+
+    def forward(self, predictions, station_positions, station_runoffs) -> torch.Tensor:
+        _need_cuda(predictions, "StationLoss")
+        pos, run, offs, S = SF.pack_stations(station_positions, station_runoffs, predictions.device)
+        if S == 0:
+            return torch.tensor(0.0, device=predictions.device)  # src/loss.py:157-158: constant, no grad
+        # the fused kernel's image term is weighted 0; the target is a same-size placeholder
+        cfg = (0, 1.0, 0.0, int(self.kernel_size), _METRIC[self.metric], 0.0, 1.0)
+        return SF.ImageStationLossFn.apply(predictions, predictions.detach(), pos, run, offs, S, cfg)[0]
+
+
+class CombinedLoss(nn.Module):
+    """Mirror of src/loss.py:163-236; config keys as src/loss.py:175-194."""
+
+    def __init__(self, config: Dict):
+        super().__init__()
+        loss_cfg = config.get("loss", {})
+        weights = loss_cfg.get("weights", {})
+        upscale = config.get("data", {}).get("upscale_factor", 2)
+        self.image_weight = weights.get("image", 1.0)
+        self.station_weight = weights.get("station", 0.5)
+        self.image_loss = ImageLoss(metric=loss_cfg.get("metric", "MSE"), upscale_factor=upscale,
+                                    nonzero_weight=float(loss_cfg.get("nonzero_weight", 10.0)),
+                                    zero_threshold=float(loss_cfg.get("zero_threshold", 1e-6)))
+        scfg = config.get("stations", {})
+        self.station_loss = StationLoss(kernel_size=scfg.get("kernel_size", 3), metric=scfg.get("metric", "MSE"))
+
+    def forward(self, predictions, targets, station_positions=None, station_runoffs=None) -> Dict[str, torch.Tensor]:
+        _need_cuda(predictions, "CombinedLoss")
+        if station_positions is not None and station_runoffs is not None:
+            pos, run, offs, S = SF.pack_stations(station_positions, station_runoffs, predictions.device)
+        else:
+            pos, run, offs, S = _no_stations(predictions)
+        il, sl = self.image_loss, self.station_loss
+        cfg = (_METRIC[il.metric], float(il.nonzero_weight), float(il.zero_threshold), int(sl.kernel_size),
+               _METRIC[sl.metric], float(self.image_weight), float(self.station_weight))
+        out = SF.ImageStationLossFn.apply(predictions, targets.to(predictions.device), pos, run, offs, S, cfg)
+        # `total` carries the gradient of the weighted sum; the two components are reported values
+        return {"total": out[0], "image": out[1].detach(), "station": out[2].detach()}

@@ -1,0 +1,493 @@
+"""ctypes bindings of libsfhip.so (the C ABI declared in include/sfhip.h).
+
+Every wrapper takes torch tensors that already live on the GPU, checks what the kernels
+assume about them (device, dtype, contiguity, shape) and enqueues the kernel on torch's
+current HIP stream.  Nothing here falls back to another implementation: if the library is
+missing or a tensor is not on the GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfhip.so")
+
+F32, BF16 = 0, 1
+OUT_NHWC, OUT_JI, OUT_IJ, OUT_OIHW = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+_c_int, _c_ll, _c_f, _c_d, _c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [("N", _c_int), ("IH", _c_int), ("IW", _c_int), ("C", _c_int),
+                ("MH", _c_int), ("MW", _c_int), ("sh", _c_int), ("sw", _c_int),
+                ("OH", _c_int), ("OW", _c_int),
+                ("osh", _c_int), ("osw", _c_int), ("ooy", _c_int), ("oox", _c_int),
+                ("ntaps", _c_int),
+                ("dy", _c_int * 16), ("dx", _c_int * 16), ("tap_rs", _c_int * 16),
+                ("cin_real", _c_int), ("RS", _c_int)]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("dtype", _c_int), ("a_kmajor", _c_int), ("b_kmajor", _c_int), ("b_gather", _c_int),
+                ("I", _c_ll), ("J", _c_ll), ("R", _c_ll),
+                ("lda", _c_ll), ("ldb", _c_ll), ("ldo", _c_ll),
+                ("nsplit", _c_int), ("out_mode", _c_int), ("out_dtype", _c_int), ("act", _c_int),
+                ("aux_mode", _c_int), ("g", ConvGeom)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                               f"(make -C {os.path.join(_HERE, 'csrc')})")
+        L = ctypes.CDLL(LIB_PATH)
+        L.sf_last_error.restype = ctypes.c_char_p
+        L.sf_transformer_save_floats.restype = ctypes.c_size_t
+        L.sf_lstm_save_floats.restype = ctypes.c_size_t
+        _lib = L
+    return _lib
+
+
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+           "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
+           "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
+           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
+           "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_transformer_save_floats",
+           "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
+           "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
+           "sf_bce_logits", "sf_adam", "sf_nan_inf_flag"]
+
+
+def _check(rc: int, who: str):
+    if rc != 0:
+        raise RuntimeError(f"{who} failed ({rc}): {lib().sf_last_error().decode()}")
+
+
+def _stream():
+    return _c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return _c_vp(t.data_ptr()) if t is not None else _c_vp(0)
+
+
+def code_of(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def epc(code: int) -> int:
+    return 8 if code == BF16 else 4
+
+
+def _dev(*ts, dtypes=None):
+    for i, t in enumerate(ts):
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("streamflow HIP ops need GPU tensors (no CPU path exists)")
+        if not t.is_contiguous():
+            raise RuntimeError("streamflow HIP ops need contiguous tensors")
+        if dtypes is not None and dtypes[i] is not None and t.dtype != dtypes[i]:
+            raise TypeError(f"argument {i}: expected {dtypes[i]}, got {t.dtype}")
+
+
+def roundup(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------ gemm / conv
+def gemm(desc: GemmDesc, A, B, out, bias=None, aux=None):
+    _dev(A, B, out, bias, aux)
+    _check(lib().sf_gemm(ctypes.byref(desc), _p(A), _p(B), _p(bias), _p(aux), _p(out), _stream()), "sf_gemm")
+
+
+def conv_geom(N, IH, IW, C, MH, MW, sh, sw, OH, OW, taps, osh=1, osw=1, ooy=0, oox=0, tap_rs=None,
+              cin_real=0, RS=0) -> ConvGeom:
+    g = ConvGeom()
+    g.N, g.IH, g.IW, g.C, g.MH, g.MW, g.sh, g.sw, g.OH, g.OW = N, IH, IW, C, MH, MW, sh, sw, OH, OW
+    g.osh, g.osw, g.ooy, g.oox = osh, osw, ooy, oox
+    g.ntaps = len(taps)
+    for t, (dy, dx) in enumerate(taps):
+        g.dy[t], g.dx[t] = dy, dx
+    if tap_rs is not None:
+        for t, v in enumerate(tap_rs):
+            g.tap_rs[t] = v
+    g.cin_real, g.RS = cin_real, RS
+    return g
+
+
+def conv_fprop(x, wp, out, geom: ConvGeom, K: int, bias=None, act=ACT_NONE, aux=None, aux_mode=0):
+    """out[NHWC] = act(conv(x) + bias) [* mask(aux)]; x NHWC, wp packed [K][taps][C]."""
+    d = GemmDesc()
+    d.dtype = code_of(x.dtype)
+    d.a_kmajor = d.b_kmajor = 0
+    d.b_gather = 1
+    d.I, d.J, d.R = K, geom.N * geom.MH * geom.MW, geom.ntaps * geom.C
+    d.lda, d.ldb, d.ldo = geom.ntaps * geom.C, geom.C, out.shape[-1]
+    d.nsplit, d.out_mode, d.out_dtype, d.act, d.aux_mode = 1, OUT_NHWC, code_of(out.dtype), act, aux_mode
+    d.g = geom
+    gemm(d, wp, x, out, bias, aux)
+
+
+def conv_wgrad(x, dout, dw, geom: ConvGeom, K: int, nsplit: Optional[int] = None):
+    """dw[OIHW f32] += sum_pixels dout[pixel][k] * x[gather(pixel, tap)][c]; dw must be zeroed."""
+    d = GemmDesc()
+    d.dtype = code_of(x.dtype)
+    d.a_kmajor = d.b_kmajor = 1
+    d.b_gather = 1
+    M = geom.N * geom.MH * geom.MW
+    d.I, d.J, d.R = K, geom.ntaps * geom.C, M
+    d.lda, d.ldb, d.ldo = dout.shape[-1], geom.C, dw.shape[0]
+    if nsplit is None:
+        tiles = ((K + 127) // 128) * ((geom.ntaps * geom.C + 127) // 128)
+        nsplit = max(1, min(M // 256, (2048 + tiles - 1) // tiles))
+    d.nsplit, d.out_mode, d.out_dtype = max(2, nsplit), OUT_OIHW, F32
+    d.g = geom
+    gemm(d, dout, x, dw)
+
+
+def linear_gemm(A, B, out, I, J, R, lda, ldb, ldo, a_km, b_km, out_mode, nsplit=1, bias=None):
+    d = GemmDesc()
+    d.dtype = code_of(A.dtype)
+    d.a_kmajor, d.b_kmajor, d.b_gather = int(a_km), int(b_km), 0
+    d.I, d.J, d.R, d.lda, d.ldb, d.ldo = I, J, R, lda, ldb, ldo
+    d.nsplit, d.out_mode, d.out_dtype = nsplit, out_mode, F32
+    gemm(d, A, B, out, bias)
+
+
+# ------------------------------------------------------------------------------ layout / packing
+def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cpad: int) -> torch.Tensor:
+    _dev(x, dtypes=[torch.float32])
+    N, C, H, W = x.shape
+    out = torch.empty((N, H, W, cpad), device=x.device, dtype=dtype)
+    _check(lib().sf_nchw_to_nhwc(_p(x), _p(out), code_of(dtype), N, C, H, W, cpad, _stream()), "sf_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, C: int) -> torch.Tensor:
+    _dev(x)
+    N, H, W, cpad = x.shape
+    out = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+    _check(lib().sf_nhwc_to_nchw(_p(x), code_of(x.dtype), _p(out), N, C, H, W, cpad, _stream()), "sf_nhwc_to_nchw")
+    return out
+
+
+def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, tap_rs: Sequence[int], transpose: bool,
+                     rows_pad: int, cols_pad: int) -> torch.Tensor:
+    _dev(w, dtypes=[torch.float32])
+    O, I, R, S = w.shape
+    out = torch.empty((rows_pad, len(tap_rs), cols_pad), device=w.device, dtype=dtype)
+    arr = (_c_int * len(tap_rs))(*tap_rs)
+    _check(lib().sf_pack_conv_weight(_p(w), _p(out), code_of(dtype), O, I, R * S, int(transpose), len(tap_rs), arr,
+                                     rows_pad, cols_pad, _stream()), "sf_pack_conv_weight")
+    return out
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _dev(x, dtypes=[torch.float32])
+    if dtype == torch.float32:
+        return x
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    _check(lib().sf_cast(_p(x), _p(out), code_of(dtype), _c_ll(x.numel()), _stream()), "sf_cast")
+    return out
+
+
+# ------------------------------------------------------------------------------ batch norm family
+def bn_stats(x: torch.Tensor, M: int, C: int, ws: torch.Tensor):
+    _dev(x, ws)
+    _check(lib().sf_bn_stats(_p(x), code_of(x.dtype), _c_ll(M), C, _p(ws), _stream()), "sf_bn_stats")
+
+
+def bn_finalize(ws, M, C, Creal, gamma, beta, rm, rv, training, momentum=0.1, eps=1e-5):
+    dev = gamma.device
+    out = torch.empty((4, C), device=dev, dtype=torch.float32)
+    _dev(gamma, beta, rm, rv, dtypes=[torch.float32] * 4)
+    _check(lib().sf_bn_finalize(_p(ws), _c_ll(M), C, Creal, _p(gamma), _p(beta), _p(rm), _p(rv), _c_f(momentum),
+                                _c_f(eps), int(training), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
+                                _stream()), "sf_bn_finalize")
+    return out  # rows: scale, shift, mean, invstd
+
+
+def bn_relu_maxpool_fwd(x, st):
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
+    _check(lib().sf_bn_relu_maxpool_fwd(_p(x), code_of(x.dtype), _p(st[0]), _p(st[1]), _p(y), N, H, W, C, _stream()),
+           "sf_bn_relu_maxpool_fwd")
+    return y
+
+
+def bn_relu_avgpool_fwd(x, st, Creal, OH, OW, out_dtype):
+    N, H, W, C = x.shape
+    y = torch.empty((N, Creal, OH, OW), device=x.device, dtype=out_dtype)
+    _check(lib().sf_bn_relu_avgpool_fwd(_p(x), code_of(x.dtype), _p(st[0]), _p(st[1]), _p(y), code_of(out_dtype), N, H,
+                                        W, C, Creal, OH, OW, _stream()), "sf_bn_relu_avgpool_fwd")
+    return y
+
+
+def bn_lrelu_fwd(x, st):
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    _check(lib().sf_bn_lrelu_fwd(_p(x), code_of(x.dtype), _p(st[0]), _p(st[1]), _p(y), _c_ll(x.numel() // C), C,
+                                 _stream()), "sf_bn_lrelu_fwd")
+    return y
+
+
+def bn_backward(mode, x, dy, st, gamma, Creal, training, OH=0, OW=0):
+    """Returns (dx, dgamma, dbeta); see sf_bn_bwd_reduce / sf_bn_bwd_apply."""
+    _dev(x, dy, st, gamma)
+    N, H, W, C = x.shape
+    ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+    c = code_of(x.dtype)
+    _check(lib().sf_bn_bwd_reduce(mode, _p(x), c, _p(dy), code_of(dy.dtype), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
+                                  _p(ws), N, H, W, C, Creal, OH, OW, _stream()), "sf_bn_bwd_reduce")
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Creal, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty(Creal, device=x.device, dtype=torch.float32)
+    _check(lib().sf_bn_bwd_apply(mode, _p(x), c, _p(dy), code_of(dy.dtype), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
+                                 _p(gamma), _p(ws), int(training), _p(dx), _p(dgamma), _p(dbeta), N, H, W, C, Creal,
+                                 OH, OW, _stream()), "sf_bn_bwd_apply")
+    return dx, dgamma, dbeta
+
+
+def channel_sum(x: torch.Tensor, Creal: int) -> torch.Tensor:
+    _dev(x)
+    C = x.shape[-1]
+    out = torch.empty(Creal, device=x.device, dtype=torch.float32)
+    ws = torch.empty(C, device=x.device, dtype=torch.float64)
+    _check(lib().sf_channel_sum(_p(x), code_of(x.dtype), _c_ll(x.numel() // C), C, Creal, _p(out), _p(ws), _stream()),
+           "sf_channel_sum")
+    return out
+
+
+def colsum_f32(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, dtypes=[torch.float32])
+    M, C = x.shape
+    out = torch.empty(C, device=x.device, dtype=torch.float32)
+    _check(lib().sf_colsum_f32(_p(x), _c_ll(M), _c_ll(C), _p(out), _stream()), "sf_colsum_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------ bilinear
+def bilinear_fwd(src_nhwc: torch.Tensor, OH: int, OW: int, dtype: torch.dtype) -> torch.Tensor:
+    _dev(src_nhwc, dtypes=[torch.float32])
+    B, h, w, C = src_nhwc.shape
+    out = torch.empty((B, OH, OW, C), device=src_nhwc.device, dtype=dtype)
+    _check(lib().sf_bilinear_fwd(_p(src_nhwc), F32, _p(out), code_of(dtype), B, C, h, w, OH, OW, C, _stream()),
+           "sf_bilinear_fwd")
+    return out
+
+
+def bilinear_bwd(ddst: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    _dev(ddst)
+    B, OH, OW, C = ddst.shape
+    tmp = torch.empty((B, OH, w, C), device=ddst.device, dtype=torch.float32)
+    out = torch.empty((B, h, w, C), device=ddst.device, dtype=torch.float32)
+    _check(lib().sf_bilinear_bwd(_p(ddst), code_of(ddst.dtype), _p(out), _p(tmp), B, C, h, w, OH, OW, C, _stream()),
+           "sf_bilinear_bwd")
+    return out
+
+
+# ------------------------------------------------------------------------------ small convs
+def dconv1_fwd(x, w, b, dtype):
+    _dev(x, w, b, dtypes=[torch.float32] * 3)
+    N, _, H, W = x.shape
+    K = w.shape[0]
+    OH, OW = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    y = torch.empty((N, OH, OW, K), device=x.device, dtype=dtype)
+    _check(lib().sf_dconv1_fwd(_p(x), _p(w), _p(b), _p(y), code_of(dtype), N, H, W, K, _stream()), "sf_dconv1_fwd")
+    return y
+
+
+def dconv1_bwd_data(dz, w, H, W):
+    _dev(dz, w)
+    N, K = dz.shape[0], dz.shape[-1]
+    dx = torch.empty((N, 1, H, W), device=dz.device, dtype=torch.float32)
+    _check(lib().sf_dconv1_bwd_data(_p(dz), code_of(dz.dtype), _p(w), _p(dx), N, H, W, K, _stream()),
+           "sf_dconv1_bwd_data")
+    return dx
+
+
+def dconv1_bwd_weight(x, dz):
+    _dev(x, dz)
+    N, _, H, W = x.shape
+    K = dz.shape[-1]
+    dw = torch.empty((K, 1, 4, 4), device=x.device, dtype=torch.float32)
+    db = torch.empty(K, device=x.device, dtype=torch.float32)
+    _check(lib().sf_dconv1_bwd_weight(_p(x), _p(dz), code_of(dz.dtype), _p(dw), _p(db), N, H, W, K, _stream()),
+           "sf_dconv1_bwd_weight")
+    return dw, db
+
+
+def conv_k1_fwd(x, w, b, R, pad):
+    _dev(x, w, b)
+    N, H, W, C = x.shape
+    Creal = w.shape[1]
+    OH, OW = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    y = torch.empty((N, 1, OH, OW), device=x.device, dtype=torch.float32)
+    _check(lib().sf_conv_k1_fwd(_p(x), code_of(x.dtype), _p(w), _p(b), _p(y), N, H, W, C, Creal, R, pad, _stream()),
+           "sf_conv_k1_fwd")
+    return y
+
+
+def conv_k1_bwd_data(dy, w, like: torch.Tensor, R, pad, relu_mask: bool):
+    """dx (same shape/dtype as `like`, the forward input); relu_mask multiplies by (like > 0)."""
+    _dev(dy, w, like)
+    N, H, W, C = like.shape
+    dx = torch.empty_like(like)
+    _check(lib().sf_conv_k1_bwd_data(_p(dy), _p(w), _p(like) if relu_mask else _c_vp(0), _p(dx), code_of(like.dtype),
+                                     N, H, W, C, w.shape[1], R, pad, _stream()), "sf_conv_k1_bwd_data")
+    return dx
+
+
+def conv_k1_bwd_weight(x, dy, Creal, R, pad):
+    _dev(x, dy)
+    N, H, W, C = x.shape
+    dw = torch.empty((1, Creal, R, R), device=x.device, dtype=torch.float32)
+    db = torch.empty(1, device=x.device, dtype=torch.float32)
+    _check(lib().sf_conv_k1_bwd_weight(_p(x), code_of(x.dtype), _p(dy), _p(dw), _p(db), N, H, W, C, Creal, R, pad,
+                                       _stream()), "sf_conv_k1_bwd_weight")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------ temporal
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    return (_c_vp * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def transformer_save_floats(T, D, F) -> int:
+    return int(lib().sf_transformer_save_floats(T, D, F))
+
+
+def transformer_layer_fwd(x, ws: List[torch.Tensor], nhead, p_drop, seed, save: Optional[torch.Tensor]):
+    _dev(x, *ws, dtypes=[torch.float32] * (1 + len(ws)))
+    B, T, D = x.shape
+    Fd = ws[4].shape[0]
+    y = torch.empty_like(x)
+    _check(lib().sf_transformer_layer_fwd(_p(x), _p(y), _ptr_array(ws), _p(save), B, T, D, Fd, nhead, _c_f(p_drop),
+                                          ctypes.c_ulonglong(seed), _stream()), "sf_transformer_layer_fwd")
+    return y
+
+
+def transformer_layer_bwd(x, dy, ws, dws, save, nhead, p_drop, seed):
+    _dev(x, dy, save, *ws, *dws)
+    B, T, D = x.shape
+    Fd = ws[4].shape[0]
+    dx = torch.empty_like(x)
+    _check(lib().sf_transformer_layer_bwd(_p(x), _p(dy), _p(dx), _ptr_array(ws), _ptr_array(dws), _p(save), B, T, D, Fd,
+                                          nhead, _c_f(p_drop), ctypes.c_ulonglong(seed), _stream()),
+           "sf_transformer_layer_bwd")
+    return dx
+
+
+def add_pe(x, pe):
+    _dev(x, pe, dtypes=[torch.float32, torch.float32])
+    B, T, D = x.shape
+    y = torch.empty_like(x)
+    _check(lib().sf_add_pe(_p(x), _p(pe), _p(y), B, T, D, _stream()), "sf_add_pe")
+    return y
+
+
+def mean_t_fwd(x):
+    B, T, D = x.shape
+    y = torch.empty((B, D), device=x.device, dtype=torch.float32)
+    _check(lib().sf_mean_t_fwd(_p(x), _p(y), B, T, D, _stream()), "sf_mean_t_fwd")
+    return y
+
+
+def mean_t_bwd(dy, T):
+    _dev(dy, dtypes=[torch.float32])
+    B, D = dy.shape
+    dx = torch.empty((B, T, D), device=dy.device, dtype=torch.float32)
+    _check(lib().sf_mean_t_bwd(_p(dy), _p(dx), B, T, D, _stream()), "sf_mean_t_bwd")
+    return dx
+
+
+def lstm_save_floats(T, H, L) -> int:
+    return int(lib().sf_lstm_save_floats(T, H, L))
+
+
+def lstm_fwd(x, ws, L, p_drop, seed, save):
+    _dev(x, *ws, dtypes=[torch.float32] * (1 + len(ws)))
+    B, T, H = x.shape
+    y = torch.empty((B, H), device=x.device, dtype=torch.float32)
+    _check(lib().sf_lstm_fwd(_p(x), _p(y), _ptr_array(ws), _p(save), B, T, H, L, _c_f(p_drop), ctypes.c_ulonglong(seed),
+                             _stream()), "sf_lstm_fwd")
+    return y
+
+
+def lstm_bwd(x, dy, ws, dws, save, L, p_drop, seed):
+    _dev(x, dy, save, *ws, *dws)
+    B, T, H = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().sf_lstm_bwd(_p(x), _p(dy), _p(dx), _ptr_array(ws), _ptr_array(dws), _p(save), B, T, H, L,
+                             _c_f(p_drop), ctypes.c_ulonglong(seed), _stream()), "sf_lstm_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------ losses / optimiser
+def lonlat_to_pixel(lon: torch.Tensor, lat: torch.Tensor, region, W: int, H: int):
+    _dev(lon, lat, dtypes=[torch.float64, torch.float64])
+    n = lon.numel()
+    px = torch.empty(n, device=lon.device, dtype=torch.int32)
+    py = torch.empty(n, device=lon.device, dtype=torch.int32)
+    _check(lib().sf_lonlat_to_pixel(_p(lon), _p(lat), n, _c_d(region[0]), _c_d(region[1]), _c_d(region[2]),
+                                    _c_d(region[3]), W, H, _p(px), _p(py), _stream()), "sf_lonlat_to_pixel")
+    return px, py
+
+
+def image_station_loss(pred, target, pos, runoff, offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
+                       station_metric, image_weight, station_weight):
+    """Returns (losses[3] = total, image, station; dpred)."""
+    _dev(pred, target, pos, runoff, offsets,
+         dtypes=[torch.float32, torch.float32, torch.int32, torch.float32, torch.int32])
+    B, _, H, W = pred.shape
+    TH, TW = target.shape[-2], target.shape[-1]
+    losses = torch.empty(3, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred)
+    ws = torch.empty(4, device=pred.device, dtype=torch.float64)
+    _check(lib().sf_image_station_loss(_p(pred), _p(target), _p(pos), _p(runoff), _p(offsets), S, B, H, W, TH, TW,
+                                       image_metric, _c_f(nonzero_weight), _c_f(zero_threshold), ksize, station_metric,
+                                       _c_f(image_weight), _c_f(station_weight), _p(losses), _p(dpred), _p(ws),
+                                       _stream()), "sf_image_station_loss")
+    return losses, dpred
+
+
+def bce_logits(x: torch.Tensor, label: float, labels: Optional[torch.Tensor] = None, need_grad: bool = True):
+    _dev(x, labels, dtypes=[torch.float32, torch.float32])
+    loss = torch.empty(1, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x) if need_grad else None
+    ws = torch.empty(1, device=x.device, dtype=torch.float64)
+    _check(lib().sf_bce_logits(_p(x), _c_ll(x.numel()), _c_f(label), _p(labels), _p(loss), _p(dx), _p(ws), _stream()),
+           "sf_bce_logits")
+    return loss, dx
+
+
+def adam(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _dev(p, g, m, v, dtypes=[torch.float32] * 4)
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    _check(lib().sf_adam(_p(p), _p(g), _p(m), _p(v), _c_ll(p.numel()), _c_f(lr), _c_f(beta1), _c_f(beta2), _c_f(eps),
+                         _c_f(bc1), _c_f(bc2), _c_f(grad_scale), _stream()), "sf_adam")
+
+
+def nan_inf_flag(x: torch.Tensor, flag: torch.Tensor):
+    _dev(x, flag, dtypes=[torch.float32, torch.int32])
+    _check(lib().sf_nan_inf_flag(_p(x), _c_ll(x.numel()), _p(flag), _stream()), "sf_nan_inf_flag")

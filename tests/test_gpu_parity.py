@@ -1,0 +1,304 @@
+"""GPU parity tests: the HIP path (through the C ABI of libsfhip.so) against the CPU oracle and
+against the golden vectors produced by the reference.  f32 mode: <= 1e-5 relative to the
+tensor's max (north-star tolerance) for forward values, looser stated bounds for gradients that
+pass through ReLU / max-pool decisions; bf16 mode: stated tolerances in each test."""
+import numpy as np
+import pytest
+import torch
+
+import goldgen as G
+from conftest import close, close_robust, golden, load_pkg
+from oracle import streamflow_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def sf():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return load_pkg()
+
+
+def load_gold(module, tag):
+    sd = module.state_dict()
+    gs = G.gold_state(G.shapes_of(sd), tag, keep={k: v.cpu() for k, v in sd.items()})
+    module.load_state_dict(gs)
+    return gs
+
+
+def cpu(t):
+    return t.detach().float().cpu()
+
+
+# ------------------------------------------------------------------ raw GEMM layouts
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("akm,bkm", [(False, False), (True, True), (True, False)])
+def test_gemm_layouts(sf, dtype, akm, bkm):
+    ops = sf.ops
+    I, J, R = 72, 200, 96
+    rs = np.random.RandomState(0)
+    A = torch.from_numpy(rs.randint(-3, 4, size=(I, R)).astype(np.float32))
+    B = torch.from_numpy(rs.randint(-3, 4, size=(J, R)).astype(np.float32))
+    ref = A @ B.t()  # exact in both dtypes (small integers)
+    Ad = (A.t().contiguous() if akm else A).to(DEV, dtype)
+    Bd = (B.t().contiguous() if bkm else B).to(DEV, dtype)
+    for mode in (ops.OUT_JI, ops.OUT_IJ):
+        out = torch.full((J, I) if mode == ops.OUT_JI else (I, J), 7.0, device=DEV)
+        ops.linear_gemm(Ad, Bd, out, I, J, R, I if akm else R, J if bkm else R, I if mode == ops.OUT_JI else J,
+                        akm, bkm, mode)
+        got = cpu(out).t() if mode == ops.OUT_JI else cpu(out)
+        assert torch.equal(got, ref), f"layout akm={akm} bkm={bkm} mode={mode} max err {(got - ref).abs().max()}"
+    # split reduction accumulates atomically into a zeroed output
+    out = torch.zeros((J, I), device=DEV)
+    ops.linear_gemm(Ad, Bd, out, I, J, R, I if akm else R, J if bkm else R, I, akm, bkm, ops.OUT_JI, nsplit=3)
+    assert torch.equal(cpu(out).t(), ref)
+
+
+def test_pixel_map_bit_exact(sf):
+    g = golden("pixel_map")
+    for ci, (region, w, h) in enumerate(G.PIXEL_CASES):
+        lon, lat = G.pixel_sweep(region, w, h)
+        px, py = sf.ops.lonlat_to_pixel(torch.from_numpy(lon).to(DEV), torch.from_numpy(lat).to(DEV), region, w, h)
+        assert np.array_equal(px.cpu().numpy(), g[f"px{ci}"])
+        assert np.array_equal(py.cpu().numpy(), g[f"py{ci}"])
+
+
+# ------------------------------------------------------------------ encoder
+@pytest.mark.parametrize("size", [64, 128, 200])
+def test_encoder_train_f32(sf, size):
+    g = golden("encoder")
+    enc = sf.CNNEncoder(4, 16, 2).to(DEV)
+    load_gold(enc, "enc")
+    enc.train()
+    x = G.gold_tensor(f"enc/x{size}", (2, 4, size, size)).to(DEV)
+    y = enc(x)
+    close(y, g[f"train{size}"], 1e-5)
+    sd = enc.state_dict()
+    close(sd["encoder.1.running_mean"], g[f"rm1_{size}"], 1e-5)
+    close(sd["encoder.1.running_var"], g[f"rv1_{size}"], 1e-5)
+    close(sd["encoder.5.running_mean"], g[f"rm2_{size}"], 1e-5)
+    close(sd["encoder.5.running_var"], g[f"rv2_{size}"], 1e-5)
+    assert int(sd["encoder.1.num_batches_tracked"]) == 1
+
+
+def test_encoder_eval_and_grads_f32(sf):
+    g = golden("encoder")
+    enc = sf.CNNEncoder(4, 16, 2).to(DEV)
+    load_gold(enc, "enc")
+    enc.eval()
+    with torch.no_grad():
+        close(enc(G.gold_tensor("enc/x128", (2, 4, 128, 128)).to(DEV)), g["eval128"], 1e-5)
+    enc.train()
+    x = G.gold_tensor("enc/x200", (2, 4, 200, 200)).to(DEV).requires_grad_(True)
+    y = enc(x)
+    (y * G.gold_tensor("enc/gy200", tuple(y.shape)).to(DEV)).sum().backward()
+    close(enc.encoder[0].weight.grad, g["g200_w0"], 1e-4)
+    close(enc.encoder[4].weight.grad, g["g200_w4"], 1e-4)
+    close(enc.encoder[1].weight.grad, g["g200_bn1w"], 1e-4)
+    close(enc.encoder[1].bias.grad, g["g200_bn1b"], 1e-4)
+    close(enc.encoder[5].weight.grad, g["g200_bn5w"], 1e-4)
+    close(enc.encoder[5].bias.grad, g["g200_bn5b"], 1e-4)
+    close_robust(x.grad[:, :, ::5, ::5], g["g200_x_sub"], 1e-4)
+
+
+def test_encoder_bf16(sf):
+    """bf16 activations / f32 accumulation and statistics: stated tolerance 3e-2 of the max."""
+    g = golden("encoder")
+    enc = sf.CNNEncoder(4, 16, 2).to(DEV)
+    load_gold(enc, "enc")
+    enc.train()
+    sf.set_compute_dtype(torch.bfloat16)
+    try:
+        y = enc(G.gold_tensor("enc/x128", (2, 4, 128, 128)).to(DEV))
+    finally:
+        sf.set_compute_dtype(None)
+    close(y, g["train128"], 3e-2)
+
+
+# ------------------------------------------------------------------ temporal
+@pytest.mark.parametrize("kind", ["tr", "lstm"])
+def test_temporal_f32(sf, kind):
+    g = golden("temporal")
+    B, T, D_in, Hd = 3, 5, 256, 32
+    if kind == "tr":
+        mod = sf.TransformerModule(D_in, Hd, num_layers=2, num_heads=4, dropout=0.0).to(DEV)
+    else:
+        mod = sf.LSTMModule(D_in, Hd, num_layers=2, dropout=0.0).to(DEV)
+    load_gold(mod, "tmp_" + kind)
+    x0 = G.gold_tensor("tmp/x", (B, T, D_in)).to(DEV)
+    mod.eval()
+    with torch.no_grad():
+        close(mod(x0), g[f"{kind}_y_eval"], 2e-5)
+    mod.train()
+    x = x0.clone().requires_grad_(True)
+    y = mod(x)
+    close(y, g[f"{kind}_y"], 1e-5)
+    (y * G.gold_tensor("tmp/gy", (B, Hd)).to(DEV)).sum().backward()
+    close(x.grad, g[f"{kind}_gx"], 5e-5)
+    for n, p in mod.named_parameters():
+        close(p.grad, g[f"{kind}_g_{n}"], 1e-4)
+
+
+def test_transformer_dropout_self_consistent(sf):
+    """Training-mode dropout cannot follow the reference's RNG stream; check the kernel's own
+    mask bookkeeping instead: same seed -> same output, and the analytic gradient matches a
+    finite difference of the SAME masked function."""
+    torch.manual_seed(3)
+    mod = sf.TransformerModule(64, 32, num_layers=1, num_heads=4, dropout=0.3).to(DEV)
+    SFn = sf.functional
+    x = torch.randn(2, 5, 32, device=DEV)
+    ws = mod._layer_weights()
+    pe = mod.pos_encoder.pe[0]
+    f = lambda inp: SFn.TransformerStackFn.apply(inp, pe, 4, 0.3, 1234, *ws)
+    y1, y2 = f(x), f(x)
+    assert torch.equal(y1, y2)
+    y0 = SFn.TransformerStackFn.apply(x, pe, 4, 0.0, 0, *ws)
+    assert (y1 - y0).abs().max() > 1e-3  # the masks do something
+    xg = x.clone().requires_grad_(True)
+    gy = torch.randn(2, 32, device=DEV)
+    (f(xg) * gy).sum().backward()
+    d = torch.randn_like(x)
+    eps = 1e-2
+    num = ((f(x + eps * d) - f(x - eps * d)) * gy).sum() / (2 * eps)
+    ana = (xg.grad * d).sum()
+    assert abs(float(num) - float(ana)) <= 2e-2 * max(1.0, abs(float(ana)))
+
+
+# ------------------------------------------------------------------ decoder
+@pytest.mark.parametrize("oh", [64, 100])
+def test_decoder_f32(sf, oh):
+    g = golden("decoder")
+    dec = sf.SimpleUpsamplingDecoder(16, oh, oh, hidden_channels=64).to(DEV)
+    load_gold(dec, "dec")
+    x = G.gold_tensor("dec/x", (2, 16, 32, 32)).to(DEV).requires_grad_(True)
+    y = dec(x)
+    close(y, g[f"y{oh}"], 1e-5)
+    (y * G.gold_tensor(f"dec/gy{oh}", tuple(y.shape)).to(DEV)).sum().backward()
+    close_robust(x.grad, g[f"gx{oh}"], 1e-4)
+    for n, p in dec.named_parameters():
+        close(p.grad, g[f"g{oh}_{n}"], 1e-3)  # a ReLU flip perturbs every weight grad slightly
+
+
+# ------------------------------------------------------------------ discriminator
+@pytest.mark.parametrize("size", [64, 50])
+def test_discriminator_f32(sf, size):
+    g = golden("discriminator")
+    d = sf.PatchDiscriminator(1, 16).to(DEV)
+    load_gold(d, "disc")
+    d.train()
+    x = G.gold_tensor(f"disc/x{size}", (2, 1, size, size)).to(DEV).requires_grad_(True)
+    y = d(x)
+    close(y, g[f"y{size}"], 2e-5)
+    (y * G.gold_tensor(f"disc/gy{size}", tuple(y.shape)).to(DEV)).sum().backward()
+    close_robust(x.grad, g[f"gx{size}"], 2e-4)
+    sd = d.state_dict()
+    for k in sd:
+        if "running" in k:
+            close(sd[k], g[f"buf{size}_{k}"], 1e-5)
+    for n, p in d.named_parameters():
+        if n in ("model.2.0.bias", "model.3.0.bias", "model.4.0.bias"):
+            assert float(p.grad.abs().max()) < 1e-4  # zero by construction (BatchNorm follows)
+        else:
+            close(p.grad, g[f"g{size}_{n}"], 1e-3)
+
+
+# ------------------------------------------------------------------ losses
+def station_cases(H, W):
+    pos = [
+        torch.tensor([[0, 0], [W - 1, H - 1], [5, 7], [6, 7], [5, 7], [W - 1, 0], [1, H - 2]], dtype=torch.int64),
+        torch.zeros((0, 2), dtype=torch.int64),
+        torch.tensor([[10, 3], [11, 4], [W // 2, H // 2]], dtype=torch.int64),
+    ]
+    run = [G.gold_tensor("loss/r0", (7,)), torch.zeros((0,)), G.gold_tensor("loss/r2", (3,))]
+    return pos, run
+
+
+def test_losses_f32(sf):
+    g = golden("losses")
+    B, H, W = 3, 40, 48
+    pred0 = G.gold_tensor("loss/pred", (B, 1, H, W)).to(DEV)
+    tgt = G.gold_tensor("loss/tgt", (B, 1, H // 2, W // 2))
+    tgt[:, :, :5, :7] = 0.0
+    tgt_same = G.gold_tensor("loss/tgt_same", (B, 1, H, W))
+    tgt_same[:, :, 10:20, :] = 0.0
+    tgt, tgt_same = tgt.to(DEV), tgt_same.to(DEV)
+    pos, run = station_cases(H, W)
+    for metric in ("MSE", "MAE"):
+        for nm, t in (("up", tgt), ("same", tgt_same)):
+            p = pred0.clone().requires_grad_(True)
+            l = sf.ImageLoss(metric=metric)(p, t)
+            l.backward()
+            close(l, g[f"img_{metric}_{nm}"], 1e-5)
+            close(p.grad, g[f"img_{metric}_{nm}_g"], 1e-5)
+        for k in (3, 5):
+            p = pred0.clone().requires_grad_(True)
+            l = sf.StationLoss(kernel_size=k, metric=metric)(p, pos, run)
+            l.backward()
+            close(l, g[f"stn_{metric}_{k}"], 1e-5)
+            close(p.grad, g[f"stn_{metric}_{k}_g"], 1e-5)
+    cfg = {"loss": {"metric": "MSE", "weights": {"image": 1.0, "station": 0.5}},
+           "stations": {"kernel_size": 5, "metric": "MSE"}, "data": {"upscale_factor": 2}}
+    p = pred0.clone().requires_grad_(True)
+    ld = sf.CombinedLoss(cfg)(p, tgt, pos, run)
+    ld["total"].backward()
+    close(ld["total"], g["comb_total"], 1e-5)
+    close(ld["image"], g["comb_image"], 1e-5)
+    close(ld["station"], g["comb_station"], 1e-5)
+    close(p.grad, g["comb_g"], 1e-5)
+    ld = sf.CombinedLoss(cfg)(pred0, tgt, [torch.zeros((0, 2), dtype=torch.int64)] * B, [torch.zeros(0)] * B)
+    close(ld["total"], g["comb_nostn_total"], 1e-5)
+    assert float(ld["station"]) == 0.0
+    gl = sf.GANLoss(0.1, 1.0)
+    lf = G.gold_tensor("loss/logit_fake", (B, 1, 11, 12), 2.0).to(DEV)
+    lr = G.gold_tensor("loss/logit_real", (B, 1, 5, 6), 2.0).to(DEV)
+    a = lf.clone().requires_grad_(True)
+    l = gl.gan_loss(a, torch.ones_like(a))
+    l.backward()
+    close(l, g["gan_g"], 1e-5)
+    close(a.grad, g["gan_g_grad"], 1e-5)
+    a = lr.clone().requires_grad_(True)
+    b = lf.clone().requires_grad_(True)
+    l = gl.discriminator_loss(a, b)
+    l.backward()
+    close(l, g["gan_d"], 1e-5)
+    close(a.grad, g["gan_d_greal"], 1e-5)
+    close(b.grad, g["gan_d_gfake"], 1e-5)
+
+
+# ------------------------------------------------------------------ generator
+def gen_cfg(hidden, temporal, size, channels):
+    return {"data": {"image_size": [size, size], "window_size": 5, "upscale_factor": 2},
+            "model": {"input_channels": channels, "hidden_dim": hidden, "num_layers": 2,
+                      "temporal_module": temporal}}
+
+
+@pytest.mark.parametrize("temporal", ["LSTM", "Transformer"])
+def test_generator_small_f32(sf, temporal):
+    g = golden("generator")
+    m = sf.StreamflowPredictionModel(gen_cfg(16, temporal, 64, 3)).to(DEV)
+    load_gold(m, "gen_" + temporal)
+    x = G.gold_tensor("gen/x", (2, 5, 3, 64, 64)).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        close(m(x), g[f"{temporal}_eval"], 2e-5)
+    m.train()
+    for mod in m.modules():
+        if hasattr(mod, "dropout") and isinstance(getattr(mod, "dropout"), float):
+            mod.dropout = 0.0
+    close(m(x), g[f"{temporal}_train"], 2e-5)
+
+
+def test_generator_full_size_f32_and_bf16(sf):
+    """The BASELINE shape: hidden 128, 10ch 200x200 -> 400x400, Transformer, one sample."""
+    g = golden("generator")
+    m = sf.StreamflowPredictionModel(gen_cfg(128, "Transformer", 200, 10)).to(DEV)
+    load_gold(m, "gen_full")
+    m.eval()
+    x = G.gold_tensor("gen_full/x", (1, 5, 10, 200, 200)).to(DEV)
+    with torch.no_grad():
+        close(m(x), g["full_eval"], 1e-5)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y16 = m(x)
+    close(y16, g["full_eval"], 3e-2)  # stated bf16 tolerance: 3e-2 of the output's max
