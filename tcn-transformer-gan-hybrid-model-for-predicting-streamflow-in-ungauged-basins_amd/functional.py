@@ -248,7 +248,7 @@ class DecoderFn(torch.autograd.Function):
         bp1 = _pad_vec(b1.detach(), Hp)
         bp2 = _pad_vec(b2.detach(), Hp)
         h1 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
-        ops.conv_fprop(up, w1p, h1, conv3x3_geom(B, OH, OW, C), Hp, bias=bp1, act=ops.ACT_RELU)
+        ops.conv_fprop(up, w1p, h1, conv3x3_geom(B, OH, OW, C), Hp, bias=bp1, act=ops.ACT_RELU, tag="dec_conv1_fprop")
         h2 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
         ops.conv_fprop(h1, w2p, h2, conv3x3_geom(B, OH, OW, Hp), Hp, bias=bp2, act=ops.ACT_RELU)
         w3c = w3.detach().contiguous()
@@ -273,13 +273,13 @@ class DecoderFn(torch.autograd.Function):
         dz1 = torch.empty_like(h1)
         ops.conv_fprop(dz2, w2T, dz1, conv3x3_geom(B, OH, OW, Hp, dgrad=True), Hp, aux=h1, aux_mode=1)
         dw1 = torch.zeros_like(w1)
-        ops.conv_wgrad(up, dz1, dw1, conv3x3_wgeom(B, OH, OW, C, C), Hp)
+        ops.conv_wgrad(up, dz1, dw1, conv3x3_wgeom(B, OH, OW, C, C), Hp, tag="dec_conv1_wgrad")
         db1 = ops.channel_sum(dz1, Hc)
         dx = None
         if ctx.needs_input_grad[0]:
             w1T = ops.pack_conv_weight(w1.detach().contiguous(), cdtype, list(range(9)), True, C, Hp)
             dup = torch.empty_like(up)
-            ops.conv_fprop(dz1, w1T, dup, conv3x3_geom(B, OH, OW, Hp, dgrad=True), C)
+            ops.conv_fprop(dz1, w1T, dup, conv3x3_geom(B, OH, OW, Hp, dgrad=True), C, tag="dec_conv1_dgrad")
             dsrc = ops.bilinear_bwd(dup, h, w)
             dx = ops.nhwc_to_nchw(dsrc, C)
         return dx, None, None, None, dw1, db1, dw2, db2, dw3, db3

@@ -115,9 +115,30 @@ def roundup(v: int, m: int) -> int:
 
 
 # ------------------------------------------------------------------------------ gemm / conv
-def gemm(desc: GemmDesc, A, B, out, bias=None, aux=None):
+# Launch timing for the benchmark's roofline line: tags listed in TIMED get a HIP event pair
+# recorded on the launch stream around each sf_gemm call carrying that tag.
+TIMED: dict = {}
+
+
+def timed_ms(tag: str):
+    """(number of launches, mean milliseconds per launch) for a timed tag; synchronises."""
+    ev = TIMED.get(tag, [])
+    if not ev:
+        return 0, 0.0
+    torch.cuda.synchronize()
+    return len(ev), sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+
+def gemm(desc: GemmDesc, A, B, out, bias=None, aux=None, tag: Optional[str] = None):
     _dev(A, B, out, bias, aux)
+    rec = TIMED.get(tag) if tag is not None else None
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(lib().sf_gemm(ctypes.byref(desc), _p(A), _p(B), _p(bias), _p(aux), _p(out), _stream()), "sf_gemm")
+    if rec is not None:
+        e1.record()
+        rec.append((e0, e1))
 
 
 def conv_geom(N, IH, IW, C, MH, MW, sh, sw, OH, OW, taps, osh=1, osw=1, ooy=0, oox=0, tap_rs=None,
@@ -135,7 +156,7 @@ def conv_geom(N, IH, IW, C, MH, MW, sh, sw, OH, OW, taps, osh=1, osw=1, ooy=0, o
     return g
 
 
-def conv_fprop(x, wp, out, geom: ConvGeom, K: int, bias=None, act=ACT_NONE, aux=None, aux_mode=0):
+def conv_fprop(x, wp, out, geom: ConvGeom, K: int, bias=None, act=ACT_NONE, aux=None, aux_mode=0, tag=None):
     """out[NHWC] = act(conv(x) + bias) [* mask(aux)]; x NHWC, wp packed [K][taps][C]."""
     d = GemmDesc()
     d.dtype = code_of(x.dtype)
@@ -145,10 +166,10 @@ def conv_fprop(x, wp, out, geom: ConvGeom, K: int, bias=None, act=ACT_NONE, aux=
     d.lda, d.ldb, d.ldo = geom.ntaps * geom.C, geom.C, out.shape[-1]
     d.nsplit, d.out_mode, d.out_dtype, d.act, d.aux_mode = 1, OUT_NHWC, code_of(out.dtype), act, aux_mode
     d.g = geom
-    gemm(d, wp, x, out, bias, aux)
+    gemm(d, wp, x, out, bias, aux, tag)
 
 
-def conv_wgrad(x, dout, dw, geom: ConvGeom, K: int, nsplit: Optional[int] = None):
+def conv_wgrad(x, dout, dw, geom: ConvGeom, K: int, nsplit: Optional[int] = None, tag=None):
     """dw[OIHW f32] += sum_pixels dout[pixel][k] * x[gather(pixel, tap)][c]; dw must be zeroed."""
     d = GemmDesc()
     d.dtype = code_of(x.dtype)
@@ -162,7 +183,7 @@ def conv_wgrad(x, dout, dw, geom: ConvGeom, K: int, nsplit: Optional[int] = None
         nsplit = max(1, min(M // 256, (2048 + tiles - 1) // tiles))
     d.nsplit, d.out_mode, d.out_dtype = max(2, nsplit), OUT_OIHW, F32
     d.g = geom
-    gemm(d, dout, x, dw)
+    gemm(d, dout, x, dw, tag=tag)
 
 
 def linear_gemm(A, B, out, I, J, R, lda, ldb, ldo, a_km, b_km, out_mode, nsplit=1, bias=None):

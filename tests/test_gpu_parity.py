@@ -302,3 +302,70 @@ def test_generator_full_size_f32_and_bf16(sf):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y16 = m(x)
     close(y16, g["full_eval"], 3e-2)  # stated bf16 tolerance: 3e-2 of the output's max
+
+
+# ------------------------------------------------------------------ train-step semantics
+def train_cfg(temporal, use_gan, accum):
+    return {
+        "data": {"image_size": [64, 64], "window_size": 5, "upscale_factor": 2},
+        "model": {"input_channels": 3, "hidden_dim": 16, "num_layers": 2, "temporal_module": temporal,
+                  "use_gan": use_gan, "gan_weight": 0.1},
+        "train": {"lr": 1e-3},
+        "loss": {"metric": "MSE", "weights": {"image": 1.0, "station": 0.5}},
+        "stations": {"kernel_size": 5, "metric": "MSE"},
+        "system": {"grad_accum_steps": accum, "mixed_precision": False},
+    }
+
+
+def make_batches(nb, B, C, size, k_seed="trn"):
+    batches = []
+    for i in range(nb):
+        pos, run = [], []
+        for b in range(B):
+            n = [3, 0, 4, 2][(i + b) % 4]
+            rs = np.random.RandomState(100 * i + b)
+            pos.append(torch.from_numpy(rs.randint(0, size, size=(n, 2)).astype(np.int64)))
+            run.append(torch.from_numpy(rs.standard_normal(n).astype(np.float32)))
+        batches.append({
+            "images": G.gold_tensor(f"{k_seed}/img{i}", (B, 5, C, size, size)),
+            "output_image": G.gold_tensor(f"{k_seed}/out{i}", (B, 1, size, size)),
+            "station_positions": pos, "stations": run,
+        })
+    return batches
+
+
+@pytest.mark.parametrize("temporal,use_gan,accum,tag", [("Transformer", True, 2, "trgan"), ("LSTM", False, 1, "lstm")])
+def test_train_epoch_semantics_f32(sf, temporal, use_gan, accum, tag):
+    """Four batches of the reference's Trainer.train_epoch (golden: loss trajectory, the
+    discriminator-schedule quirk, final parameter checksums after the fused Adam updates)."""
+    import importlib
+    training = importlib.import_module(sf.__name__ + ".training")
+    g = golden("train")
+    tr = training.Trainer(train_cfg(temporal, use_gan, accum), device=DEV)
+    load_gold(tr.model, "trn_g_" + tag)
+    tr.model.temporal_module.dropout = 0.0
+    if use_gan:
+        load_gold(tr.discriminator, "trn_d_" + tag)
+    rows = []
+    for b in make_batches(4, 2, 3, 64):
+        o = tr.train_step(b["images"], b["output_image"], b["station_positions"], b["stations"])
+        rows.append([float(o["total"]), float(o["image"]), float(o["station"]),
+                     float(o["gan_g"]) if "gan_g" in o else np.nan, float(o["gan_d"]) if "gan_d" in o else np.nan])
+    rows = np.array(rows)
+    ref = g[f"{tag}_losses"]
+    assert np.array_equal(np.isnan(rows), np.isnan(ref))
+    np.testing.assert_allclose(np.nan_to_num(rows), np.nan_to_num(ref), rtol=5e-4)
+    assert not tr.saw_nan_or_inf()
+    gsd = {k: v.cpu() for k, v in tr.model.state_dict().items()}
+    keys = [str(k) for k in g[f"{tag}_gkeys"]]
+    cs = G.checksum(gsd, keys)
+    np.testing.assert_allclose(np.stack([cs[k] for k in keys])[:, 1], g[f"{tag}_gsum"][:, 1], rtol=5e-4)
+    close(gsd["decoder.output_conv.weight"], g[f"{tag}_g_dec_out_w"], 2e-3)
+    close(gsd["cnn_encoder.encoder.1.running_mean"], g[f"{tag}_g_bn1_rm"], 1e-4)
+    if use_gan:
+        dsd = {k: v.cpu() for k, v in tr.discriminator.state_dict().items()}
+        keys = [str(k) for k in g[f"{tag}_dkeys"]]
+        cs = G.checksum(dsd, keys)
+        np.testing.assert_allclose(np.stack([cs[k] for k in keys])[:, 1], g[f"{tag}_dsum"][:, 1], rtol=5e-4)
+        close(dsd["model.5.bias"], g[f"{tag}_d_m5_b"], 2e-3)
+        close(dsd["model.2.1.running_var"], g[f"{tag}_d_bn2_rv"], 1e-4)
