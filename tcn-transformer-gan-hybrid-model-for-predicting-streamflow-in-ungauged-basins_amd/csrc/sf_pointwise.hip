@@ -424,19 +424,38 @@ __global__ void bn_bwd_reduce_kernel(BnBwd a, double* __restrict__ ws) {
     }
 }
 
+// Per-channel-group constants of the BN backward, reloaded only when the group changes (a
+// thread keeps its group across the grid-stride loop whenever the group count divides 256).
+template <int EPC> struct BnChan {
+    int cg = -1;
+    float sc[EPC], mu[EPC], is[EPC], m1[EPC], m2[EPC];
+    __device__ __forceinline__ void load(const BnBwd& a, const double* __restrict__ ws, int g, double inv_m) {
+        if (g == cg) return;
+        cg = g;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = g * EPC + e;
+            sc[e] = a.scale[c]; mu[e] = a.mean[c]; is[e] = a.invstd[c];
+            m1[e] = a.training ? (float)(ws[c] * inv_m) : 0.f;
+            m2[e] = a.training ? (float)(ws[a.C + c] * inv_m) : 0.f;
+        }
+    }
+};
+
 template <typename T, int MODE>
 __global__ void bn_bwd_apply_kernel(BnBwd a, const double* __restrict__ ws, T* __restrict__ dx,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
     constexpr int EPC = ElemTraits<T>::EPC;
     const int G = a.C / EPC;
     const T* x = reinterpret_cast<const T*>(a.x);
-    const double Mtot = (double)a.N * a.H * a.W;
+    const double inv_m = 1.0 / ((double)a.N * a.H * a.W);
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < a.Creal; c += NT) {
             if (dgamma) dgamma[c] = (float)ws[a.C + c];
             if (dbeta) dbeta[c] = (float)ws[c];
         }
     }
+    BnChan<EPC> ch;
     if (MODE == 0) {
         const int WH = (a.H + 1) / 2, WW = (a.W + 1) / 2;
         const long long total = (long long)a.N * WH * WW * G;
@@ -446,6 +465,7 @@ __global__ void bn_bwd_apply_kernel(BnBwd a, const double* __restrict__ ws, T* _
             const int pw = (int)(r % WW); r /= WW;
             const int ph = (int)(r % WH);
             const long long n = r / WH;
+            ch.load(a, ws, cg, inv_m);
             float xf[4][EPC], dz[4][EPC];
             bool valid[4];
             dz_window<T>(a, n, ph, pw, cg, xf, valid, dz);
@@ -456,15 +476,8 @@ __global__ void bn_bwd_apply_kernel(BnBwd a, const double* __restrict__ ws, T* _
                 float out[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const int c = cg * EPC + e;
-                    const float xh = (xf[k][e] - a.mean[c]) * a.invstd[c];
-                    const float sc = a.scale[c];
-                    if (a.training) {
-                        const float m1 = (float)(ws[c] / Mtot), m2 = (float)(ws[a.C + c] / Mtot);
-                        out[e] = sc * (dz[k][e] - m1 - xh * m2);
-                    } else {
-                        out[e] = sc * dz[k][e];
-                    }
+                    const float xh = (xf[k][e] - ch.mu[e]) * ch.is[e];
+                    out[e] = ch.sc[e] * (dz[k][e] - ch.m1[e] - xh * ch.m2[e]);
                 }
                 store_chunk<T>(dx + ((n * a.H + h) * a.W + w) * a.C + cg * EPC, out);
             }
@@ -478,19 +491,14 @@ __global__ void bn_bwd_apply_kernel(BnBwd a, const double* __restrict__ ws, T* _
             const long long t = r / a.W;
             const int h = (int)(t % a.H);
             const long long n = t / a.H;
+            ch.load(a, ws, cg, inv_m);
             float xf[EPC], dz[EPC], out[EPC];
             load_chunk<T>(x + o * EPC, xf);
             dz_at<T, MODE>(a, n, h, w, cg, xf, dz);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                const int c = cg * EPC + e;
-                const float xh = (xf[e] - a.mean[c]) * a.invstd[c];
-                if (a.training) {
-                    const float m1 = (float)(ws[c] / Mtot), m2 = (float)(ws[a.C + c] / Mtot);
-                    out[e] = a.scale[c] * (dz[e] - m1 - xh * m2);
-                } else {
-                    out[e] = a.scale[c] * dz[e];
-                }
+                const float xh = (xf[e] - ch.mu[e]) * ch.is[e];
+                out[e] = ch.sc[e] * (dz[e] - ch.m1[e] - xh * ch.m2[e]);
             }
             store_chunk<T>(dx + o * EPC, out);
         }
