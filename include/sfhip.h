@@ -76,6 +76,29 @@ typedef struct sf_gemm_desc {
 int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, const float* bias,
             const void* aux, void* out, void* stream);
 
+/*
+ * 3x3 stride-1 convolution, bf16 NHWC, forward or data gradient (nn.Conv2d(k=3,p=1) at
+ * src/model/cnn_encoder.py:45-51 and src/model/decoder.py:148-150): the (TH+2)x(TW+2) halo
+ * patch of each input-channel chunk is staged in LDS once and shared by all nine taps.
+ * in [N,H,W,C] (C % 16 == 0); wp packed [K][9][C]; tap t reads the input at offset
+ * (dy[t], dx[t]) in [-1,1]^2 (host arrays of 9 ints); out NHWC [N,H,W,ldo] (out_dtype);
+ * bias f32 [K] or NULL; act / aux / aux_mode as in sf_gemm_desc.
+ */
+int sf_conv3x3(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N,
+               int H, int W, int C, int K, int ldo, const int* dy, const int* dx, int act,
+               int aux_mode, int out_dtype, void* stream);
+
+/*
+ * Weight gradient of the same 3x3 stride-1 convolution (bf16 NHWC):
+ * dw[k][c][t] (f32 OIHW, overwritten) = sum_pixels dout[pixel][k] * x[pixel + (dy[t],dx[t])][c].
+ * x [N,H,W,Cx], dout [N,H,W,Kd] (channel strides, multiples of 8); K, Cin = real channel counts.
+ * ws: caller-provided scratch of sf_wgrad3x3_workspace_bytes(...) bytes (per-slice partial
+ * sums, reduced in a fixed order: results are bitwise reproducible).
+ */
+size_t sf_wgrad3x3_workspace_bytes(int N, int H, int W, int K, int Cin);
+int sf_wgrad3x3(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, int N, int H,
+                int W, int Cx, int Kd, int K, int Cin, const int* dy, const int* dx, void* stream);
+
 /* ---- layout / packing -------------------------------------------------------------- */
 /* NCHW f32 -> NHWC (dtype) with channels zero-padded to Cpad. (images.view at src/model/__init__.py:125) */
 int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad,

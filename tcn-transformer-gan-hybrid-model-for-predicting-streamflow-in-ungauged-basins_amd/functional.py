@@ -62,7 +62,7 @@ class EncoderFn(torch.autograd.Function):
         L = len(params) // 5
         N, Cin, H, W = x.shape
         e = ops.epc(ops.code_of(cdtype))
-        a = ops.nchw_to_nhwc(x.contiguous(), cdtype, ops.roundup(Cin, e))
+        a = ops.nchw_to_nhwc(x.contiguous(), cdtype, ops.roundup(Cin, 16 if cdtype == torch.bfloat16 else e))
         saved = []
         h, w = H, W
         out = None
@@ -73,7 +73,7 @@ class EncoderFn(torch.autograd.Function):
             C = a.shape[-1]
             wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), False, Kpad, C)
             z = torch.empty((N, h, w, Kpad), device=x.device, dtype=cdtype)
-            ops.conv_fprop(a, wp, z, conv3x3_geom(N, h, w, C), Kpad)
+            ops.conv3x3(a, wp, z, Kpad)
             M = N * h * w
             ws = None
             if training:
@@ -111,13 +111,13 @@ class EncoderFn(torch.autograd.Function):
             cin_real = wt.shape[1]
             mode = 1 if l == L - 1 else 0
             dz, dgamma, dbeta = ops.bn_backward(mode, z, dy, st, gamma.detach(), K, training, oh, ow)
-            dw = torch.zeros_like(wt)
-            ops.conv_wgrad(a, dz, dw, conv3x3_wgeom(N, h, w, C, cin_real), Kpad)
+            dw = torch.empty_like(wt)
+            ops.wgrad3x3(a, dz, dw)
             grads[5 * l], grads[5 * l + 1], grads[5 * l + 2] = dw, dgamma, dbeta
             if l > 0 or ctx.needs_input_grad[0]:
                 wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), True, C, Kpad)
                 da = torch.empty((N, h, w, C), device=dz.device, dtype=cdtype)
-                ops.conv_fprop(dz, wT, da, conv3x3_geom(N, h, w, Kpad, dgrad=True), C)
+                ops.conv3x3(dz, wT, da, C, dgrad=True)
                 if l > 0:
                     dy = da
                 else:
@@ -248,9 +248,9 @@ class DecoderFn(torch.autograd.Function):
         bp1 = _pad_vec(b1.detach(), Hp)
         bp2 = _pad_vec(b2.detach(), Hp)
         h1 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
-        ops.conv_fprop(up, w1p, h1, conv3x3_geom(B, OH, OW, C), Hp, bias=bp1, act=ops.ACT_RELU, tag="dec_conv1_fprop")
+        ops.conv3x3(up, w1p, h1, Hp, bias=bp1, act=ops.ACT_RELU, tag="dec_conv1_fprop")
         h2 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
-        ops.conv_fprop(h1, w2p, h2, conv3x3_geom(B, OH, OW, Hp), Hp, bias=bp2, act=ops.ACT_RELU)
+        ops.conv3x3(h1, w2p, h2, Hp, bias=bp2, act=ops.ACT_RELU)
         w3c = w3.detach().contiguous()
         y = ops.conv_k1_fwd(h2, w3c, b3.detach().contiguous(), 1, 0)
         ctx.save_for_backward(up, h1, h2, w3c)
@@ -266,20 +266,20 @@ class DecoderFn(torch.autograd.Function):
         dy = dy.contiguous().float()
         dw3, db3 = ops.conv_k1_bwd_weight(h2, dy, Hc, 1, 0)
         dz2 = ops.conv_k1_bwd_data(dy, w3c, h2, 1, 0, relu_mask=True)
-        dw2 = torch.zeros_like(w2)
-        ops.conv_wgrad(h1, dz2, dw2, conv3x3_wgeom(B, OH, OW, Hp, Hc), Hp)
+        dw2 = torch.empty_like(w2)
+        ops.wgrad3x3(h1, dz2, dw2)
         db2 = ops.channel_sum(dz2, Hc)
         w2T = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), True, Hp, Hp)
         dz1 = torch.empty_like(h1)
-        ops.conv_fprop(dz2, w2T, dz1, conv3x3_geom(B, OH, OW, Hp, dgrad=True), Hp, aux=h1, aux_mode=1)
-        dw1 = torch.zeros_like(w1)
-        ops.conv_wgrad(up, dz1, dw1, conv3x3_wgeom(B, OH, OW, C, C), Hp, tag="dec_conv1_wgrad")
+        ops.conv3x3(dz2, w2T, dz1, Hp, dgrad=True, aux=h1, aux_mode=1)
+        dw1 = torch.empty_like(w1)
+        ops.wgrad3x3(up, dz1, dw1, tag="dec_conv1_wgrad")
         db1 = ops.channel_sum(dz1, Hc)
         dx = None
         if ctx.needs_input_grad[0]:
             w1T = ops.pack_conv_weight(w1.detach().contiguous(), cdtype, list(range(9)), True, C, Hp)
             dup = torch.empty_like(up)
-            ops.conv_fprop(dz1, w1T, dup, conv3x3_geom(B, OH, OW, Hp, dgrad=True), C, tag="dec_conv1_dgrad")
+            ops.conv3x3(dz1, w1T, dup, C, dgrad=True, tag="dec_conv1_dgrad")
             dsrc = ops.bilinear_bwd(dup, h, w)
             dx = ops.nhwc_to_nchw(dsrc, C)
         return dx, None, None, None, dw1, db1, dw2, db2, dw3, db3

@@ -55,11 +55,12 @@ def lib():
         L.sf_last_error.restype = ctypes.c_char_p
         L.sf_transformer_save_floats.restype = ctypes.c_size_t
         L.sf_lstm_save_floats.restype = ctypes.c_size_t
+        L.sf_wgrad3x3_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 
 
-EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_conv3x3", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
@@ -115,6 +116,10 @@ def roundup(v: int, m: int) -> int:
 
 
 # ------------------------------------------------------------------------------ gemm / conv
+# Debug switch: route bf16 3x3 convolutions through the generic implicit-GEMM kernel instead of
+# the LDS-patch kernels (used by tests to cross-check the two implementations).
+FORCE_GENERIC_CONV = False
+
 # Launch timing for the benchmark's roofline line: tags listed in TIMED get a HIP event pair
 # recorded on the launch stream around each sf_gemm call carrying that tag.
 TIMED: dict = {}
@@ -167,6 +172,60 @@ def conv_fprop(x, wp, out, geom: ConvGeom, K: int, bias=None, act=ACT_NONE, aux=
     d.nsplit, d.out_mode, d.out_dtype, d.act, d.aux_mode = 1, OUT_NHWC, code_of(out.dtype), act, aux_mode
     d.g = geom
     gemm(d, wp, x, out, bias, aux, tag)
+
+
+def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0, tag=None):
+    """3x3 stride-1 pad-1 conv (dgrad=False) or its data gradient (dgrad=True; wp packed
+    transposed).  bf16 tensors with C % 16 == 0 take the LDS-patch kernel, everything else the
+    generic implicit GEMM."""
+    N, H, W, C = x.shape
+    if dgrad:
+        taps = [(1 - r, 1 - s) for r in range(3) for s in range(3)]
+    else:
+        taps = [(r - 1, s - 1) for r in range(3) for s in range(3)]
+    if x.dtype == torch.bfloat16 and C % 16 == 0 and not FORCE_GENERIC_CONV:
+        _dev(x, wp, out, bias, aux)
+        rec = TIMED.get(tag) if tag is not None else None
+        if rec is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dy = (_c_int * 9)(*[t[0] for t in taps])
+        dx = (_c_int * 9)(*[t[1] for t in taps])
+        _check(lib().sf_conv3x3(_p(x), _p(wp), _p(bias), _p(aux), _p(out), N, H, W, C, K, out.shape[-1], dy, dx, act,
+                                aux_mode, code_of(out.dtype), _stream()), "sf_conv3x3")
+        if rec is not None:
+            e1.record()
+            rec.append((e0, e1))
+        return
+    geom = conv_geom(N, H, W, C, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)))
+    conv_fprop(x, wp, out, geom, K, bias=bias, act=act, aux=aux, aux_mode=aux_mode, tag=tag)
+
+
+def wgrad3x3(x, dout, dw, tag=None):
+    """dw[OIHW f32] = weight gradient of a 3x3 stride-1 pad-1 conv; x / dout NHWC.  bf16 tensors
+    take the LDS-patch kernel (deterministic slab reduction); f32 the generic GEMM with atomics."""
+    N, H, W, Cx = x.shape
+    K, Cin = dw.shape[0], dw.shape[1]
+    taps = [(r - 1, s - 1) for r in range(3) for s in range(3)]
+    if x.dtype == torch.bfloat16 and not FORCE_GENERIC_CONV:
+        _dev(x, dout, dw)
+        nbytes = int(lib().sf_wgrad3x3_workspace_bytes(N, H, W, K, Cin))
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        rec = TIMED.get(tag) if tag is not None else None
+        if rec is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dy = (_c_int * 9)(*[t[0] for t in taps])
+        dx = (_c_int * 9)(*[t[1] for t in taps])
+        _check(lib().sf_wgrad3x3(_p(x), _p(dout), _p(dw), _p(ws), ctypes.c_size_t(nbytes), N, H, W, Cx, dout.shape[-1],
+                                 K, Cin, dy, dx, _stream()), "sf_wgrad3x3")
+        if rec is not None:
+            e1.record()
+            rec.append((e0, e1))
+        return
+    dw.zero_()
+    geom = conv_geom(N, H, W, Cx, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)), cin_real=Cin, RS=9)
+    conv_wgrad(x, dout, dw, geom, dout.shape[-1], tag=tag)
 
 
 def conv_wgrad(x, dout, dw, geom: ConvGeom, K: int, nsplit: Optional[int] = None, tag=None):

@@ -369,3 +369,75 @@ def test_train_epoch_semantics_f32(sf, temporal, use_gan, accum, tag):
         np.testing.assert_allclose(np.stack([cs[k] for k in keys])[:, 1], g[f"{tag}_dsum"][:, 1], rtol=5e-4)
         close(dsd["model.5.bias"], g[f"{tag}_d_m5_b"], 2e-3)
         close(dsd["model.2.1.running_var"], g[f"{tag}_d_bn2_rv"], 1e-4)
+
+
+# ------------------------------------------------------------------ bf16 backward (LDS-patch conv kernels)
+def _bf16_fwd_bwd(sf, which, generic):
+    sf.ops.FORCE_GENERIC_CONV = generic
+    sf.set_compute_dtype(torch.bfloat16)
+    try:
+        if which == "dec":
+            m = sf.SimpleUpsamplingDecoder(16, 100, 100, hidden_channels=64).to(DEV)
+            load_gold(m, "dec")
+            x = G.gold_tensor("dec/x", (2, 16, 32, 32)).to(DEV).requires_grad_(True)
+            gy = "dec/gy100"
+        else:
+            m = sf.CNNEncoder(4, 16, 2).to(DEV)
+            load_gold(m, "enc")
+            m.train()
+            x = G.gold_tensor("enc/x200", (2, 4, 200, 200)).to(DEV).requires_grad_(True)
+            gy = "enc/gy200"
+        y = m(x)
+        (y * G.gold_tensor(gy, tuple(y.shape)).to(DEV)).sum().backward()
+    finally:
+        sf.set_compute_dtype(None)
+        sf.ops.FORCE_GENERIC_CONV = False
+    out = {"y": y.detach().cpu(), "gx": x.grad.cpu()}
+    out.update({n: p.grad.cpu() for n, p in m.named_parameters()})
+    return out
+
+
+@pytest.mark.parametrize("which", ["dec", "enc"])
+def test_bf16_backward(sf, which):
+    """bf16 mode runs the 3x3 LDS-patch kernels (forward, data gradient, weight gradient).
+    (a) They must agree with the generic implicit-GEMM kernels on the same bf16 operands to
+    2e-3 of each tensor's max (different f32 summation order only).  (b) Against the reference's
+    f32 gradients the stated bf16 tolerance is 0.15 of the max: bf16 rounding flips the ReLU /
+    max-pool decision of the ~0.3 % of pre-activations that lie within rounding of zero, and with
+    the random upstream gradient used here those flips alone are worth ~sqrt(0.003) = 5 %."""
+    a = _bf16_fwd_bwd(sf, which, generic=False)
+    b = _bf16_fwd_bwd(sf, which, generic=True)
+    for k in a:
+        close(a[k], b[k].numpy(), 2e-3)
+    if which == "dec":
+        g = golden("decoder")
+        close(a["y"], g["y100"], 3e-2)
+        close_robust(a["gx"], g["gx100"], 0.15, frac=0.01, loose=0.5)
+        for n in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "output_conv.weight", "output_conv.bias"):
+            close(a[n], g["g100_" + n], 0.15)
+    else:
+        g = golden("encoder")
+        close(a["y"], g["train200"], 3e-2)
+        for n, k in (("encoder.0.weight", "g200_w0"), ("encoder.4.weight", "g200_w4"), ("encoder.1.weight", "g200_bn1w"),
+                     ("encoder.1.bias", "g200_bn1b"), ("encoder.5.weight", "g200_bn5w"), ("encoder.5.bias", "g200_bn5b")):
+            close(a[n], g[k], 0.15)
+
+
+def test_wgrad3x3_matches_generic(sf):
+    """The slab-reduced LDS-patch weight gradient against the generic GEMM path on the same bf16
+    operands (both accumulate in f32): odd sizes, partial tiles, channel counts below one tile."""
+    ops = sf.ops
+    torch.manual_seed(0)
+    for (N, H, W, C, K) in [(2, 37, 53, 16, 24), (1, 100, 100, 64, 64), (3, 20, 200, 136, 72)]:
+        x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+        dz = torch.randn(N, H, W, K, device=DEV).to(torch.bfloat16)
+        dw_a = torch.empty(K, C, 3, 3, device=DEV)
+        ops.wgrad3x3(x, dz, dw_a)
+        dw_b = torch.zeros(K, C, 3, 3, device=DEV)
+        taps = [(r - 1, s - 1) for r in range(3) for s in range(3)]
+        geom = ops.conv_geom(N, H, W, C, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)), cin_real=C, RS=9)
+        ops.conv_wgrad(x, dz, dw_b, geom, K)
+        close(dw_a, dw_b.cpu().numpy(), 1e-4)
+        ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2).cpu(), (K, C, 3, 3),
+                                          dz.float().permute(0, 3, 1, 2).cpu(), padding=1)
+        close(dw_a, ref.numpy(), 1e-4)
