@@ -89,15 +89,21 @@ int sf_conv3x3(const void* in, const void* wp, const float* bias, const void* au
                int aux_mode, int out_dtype, void* stream);
 
 /*
- * Weight gradient of the same 3x3 stride-1 convolution (bf16 NHWC):
- * dw[k][c][t] (f32 OIHW, overwritten) = sum_pixels dout[pixel][k] * x[pixel + (dy[t],dx[t])][c].
- * x [N,H,W,Cx], dout [N,H,W,Kd] (channel strides, multiples of 8); K, Cin = real channel counts.
- * ws: caller-provided scratch of sf_wgrad3x3_workspace_bytes(...) bytes (per-slice partial
- * sums, reduced in a fixed order: results are bitwise reproducible).
+ * Convolution weight gradients, bf16 NHWC, f32 OIHW result (overwritten):
+ *   sf_wgrad3x3:   3x3 stride 1 pad 1 (src/model/cnn_encoder.py:45-51, src/model/decoder.py:148-150)
+ *                  dw[k][c][r*3+s] = sum_pixels dout[y][x][k] * x[y+r-1][x+s-1][c]
+ *   sf_wgrad4x4s2: 4x4 stride 2 pad 1 (src/model/gan.py:26-31)
+ *                  dw[k][c][r*4+s] = sum_pixels dout[oy][ox][k] * x[2*oy+r-1][2*ox+s-1][c]
+ * x [N,H,W,Cx], dout [N,OH,OW,Kd] (Cx, Kd = channel strides, multiples of 8); K, Cin = real
+ * channel counts of dw.  ws: caller-provided scratch of *_workspace_bytes(...) bytes holding
+ * per-slice partial sums that are reduced in a fixed order (bitwise reproducible, no atomics).
  */
 size_t sf_wgrad3x3_workspace_bytes(int N, int H, int W, int K, int Cin);
 int sf_wgrad3x3(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, int N, int H,
-                int W, int Cx, int Kd, int K, int Cin, const int* dy, const int* dx, void* stream);
+                int W, int Cx, int Kd, int K, int Cin, void* stream);
+size_t sf_wgrad4x4s2_workspace_bytes(int N, int IH, int IW, int K, int Cin);
+int sf_wgrad4x4s2(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, int N, int IH,
+                  int IW, int Cx, int Kd, int K, int Cin, void* stream);
 
 /* ---- layout / packing -------------------------------------------------------------- */
 /* NCHW f32 -> NHWC (dtype) with channels zero-padded to Cpad. (images.view at src/model/__init__.py:125) */

@@ -42,6 +42,7 @@ template <int NV, typename F>
 __device__ __forceinline__ void reduce_phases_atomic(const float* vals, int G, int rpp, float* sm /*[8][NT]*/,
                                                      float* out, F out_index) {
     const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+#pragma unroll
     for (int v0 = 0; v0 < NV; v0 += 8) {
         __syncthreads();
 #pragma unroll
@@ -367,7 +368,7 @@ extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, f
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const int rpp = NT / (K / epc);
     const long long M = (long long)N * OH * OW;
-    int grid = (int)((M + rpp - 1) / rpp); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
+    int grid = (int)((M + rpp * 16 - 1) / (rpp * 16)); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
     DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_bwd_weight_kernel<T>, dim3(grid), dim3(NT), 0, s, x, (const T*)dz, dw,
                                          db, N, H, W, K, OH, OW));
     SF_LAUNCH_CHECK("sf_dconv1_bwd_weight");
@@ -434,7 +435,7 @@ extern "C" int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, 
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const int rpp = NT / (C / epc);
     const long long M = (long long)N * OH * OW;
-    int grid = (int)((M + rpp - 1) / rpp); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+    int grid = (int)((M + rpp * 16 - 1) / (rpp * 16)); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
     if (R == 1) {
         DISPATCH_T(dtype, hipLaunchKernelGGL((conv_k1_bwd_weight_kernel<T, 1>), dim3(grid), dim3(NT), 0, s, (const T*)x,
                                              dy, dw, db, N, H, W, C, Creal, R, pad, OH, OW));

@@ -686,7 +686,7 @@ extern "C" int sf_bn_stats(const void* x, int dtype, long long M, int C, double*
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { sf_set_error("sf_bn_stats: memset failed"); return SF_ELAUNCH; }
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
-    int grid = (int)((M + rpp - 1) / rpp); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    int grid = (int)((M + rpp * 8 - 1) / (rpp * 8)); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, true>), dim3(grid), dim3(NT), 0, s, (const T*)x, M, C, ws));
     SF_LAUNCH_CHECK("sf_bn_stats");
     return SF_OK;
@@ -706,7 +706,7 @@ extern "C" int sf_channel_sum(const void* x, int dtype, long long M, int C, int 
     if (hipMemsetAsync(ws, 0, sizeof(double) * C, s) != hipSuccess) { sf_set_error("sf_channel_sum: memset failed"); return SF_ELAUNCH; }
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
-    int grid = (int)((M + rpp - 1) / rpp); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    int grid = (int)((M + rpp * 8 - 1) / (rpp * 8)); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, false>), dim3(grid), dim3(NT), 0, s, (const T*)x, M, C, ws));
     hipLaunchKernelGGL(ws_to_float_kernel, dim3(1), dim3(NT), 0, s, ws, out, Creal);
     SF_LAUNCH_CHECK("sf_channel_sum");
@@ -794,7 +794,7 @@ extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* 
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
     const long long items = mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
-    int grid = (int)((items + rpp - 1) / rpp); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    int grid = (int)((items + rpp * 8 - 1) / (rpp * 8)); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
 #define RED(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), dim3(grid), dim3(NT), 0, s, a, ws))
     if (mode == 0) { RED(0); } else if (mode == 1) { RED(1); } else { RED(2); }
 #undef RED

@@ -380,8 +380,8 @@ class DiscriminatorFn(torch.autograd.Function):
             K, C = wt.shape[0], yin.shape[-1]
             ih, iw, oh, ow = yin.shape[1], yin.shape[2], z.shape[1], z.shape[2]
             dz, dgamma, dbeta = ops.bn_backward(2, z, dy, st, gamma.detach(), K, True)
-            dw = torch.zeros_like(wt)
-            ops.conv_wgrad(yin, dz, dw, _s2_wgeom(N, ih, iw, C, oh, ow, C), K)
+            dw = torch.empty_like(wt)
+            ops.wgrad4x4s2(yin, dz, dw)
             db = ops.channel_sum(dz, K)
             grads[2 + 6 * i], grads[2 + 6 * i + 1] = dw, db
             grads[2 + 6 * i + 2], grads[2 + 6 * i + 3] = dgamma, dbeta

@@ -56,11 +56,12 @@ def lib():
         L.sf_transformer_save_floats.restype = ctypes.c_size_t
         L.sf_lstm_save_floats.restype = ctypes.c_size_t
         L.sf_wgrad3x3_workspace_bytes.restype = ctypes.c_size_t
+        L.sf_wgrad4x4s2_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 
 
-EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_conv3x3", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_conv3x3", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
@@ -215,16 +216,32 @@ def wgrad3x3(x, dout, dw, tag=None):
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        dy = (_c_int * 9)(*[t[0] for t in taps])
-        dx = (_c_int * 9)(*[t[1] for t in taps])
         _check(lib().sf_wgrad3x3(_p(x), _p(dout), _p(dw), _p(ws), ctypes.c_size_t(nbytes), N, H, W, Cx, dout.shape[-1],
-                                 K, Cin, dy, dx, _stream()), "sf_wgrad3x3")
+                                 K, Cin, _stream()), "sf_wgrad3x3")
         if rec is not None:
             e1.record()
             rec.append((e0, e1))
         return
     dw.zero_()
     geom = conv_geom(N, H, W, Cx, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)), cin_real=Cin, RS=9)
+    conv_wgrad(x, dout, dw, geom, dout.shape[-1], tag=tag)
+
+
+def wgrad4x4s2(x, dout, dw, tag=None):
+    """dw[OIHW f32] = weight gradient of a 4x4 stride-2 pad-1 conv; x [N,IH,IW,C], dout [N,OH,OW,K]."""
+    N, IH, IW, Cx = x.shape
+    OH, OW = dout.shape[1], dout.shape[2]
+    K, Cin = dw.shape[0], dw.shape[1]
+    if x.dtype == torch.bfloat16 and not FORCE_GENERIC_CONV:
+        _dev(x, dout, dw)
+        nbytes = int(lib().sf_wgrad4x4s2_workspace_bytes(N, IH, IW, K, Cin))
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        _check(lib().sf_wgrad4x4s2(_p(x), _p(dout), _p(dw), _p(ws), ctypes.c_size_t(nbytes), N, IH, IW, Cx,
+                                   dout.shape[-1], K, Cin, _stream()), "sf_wgrad4x4s2")
+        return
+    dw.zero_()
+    taps = [(r - 1, s - 1) for r in range(4) for s in range(4)]
+    geom = conv_geom(N, IH, IW, Cx, OH, OW, 2, 2, OH, OW, taps, tap_rs=list(range(16)), cin_real=Cin, RS=16)
     conv_wgrad(x, dout, dw, geom, dout.shape[-1], tag=tag)
 
 

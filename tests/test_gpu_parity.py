@@ -441,3 +441,19 @@ def test_wgrad3x3_matches_generic(sf):
         ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2).cpu(), (K, C, 3, 3),
                                           dz.float().permute(0, 3, 1, 2).cpu(), padding=1)
         close(dw_a, ref.numpy(), 1e-4)
+
+
+def test_wgrad4x4s2_matches_reference(sf):
+    """Stride-2 4x4 weight gradient (PatchGAN layers) against torch's f32 conv2d_weight on the
+    same bf16 operands: odd / even input sizes, partial tiles, several channel tiles."""
+    ops = sf.ops
+    torch.manual_seed(1)
+    for (N, IH, IW, C, K) in [(2, 50, 50, 16, 32), (1, 25, 25, 64, 128), (3, 100, 36, 136, 72), (2, 12, 12, 256, 512)]:
+        OH, OW = (IH - 2) // 2 + 1, (IW - 2) // 2 + 1
+        x = torch.randn(N, IH, IW, C, device=DEV).to(torch.bfloat16)
+        dz = torch.randn(N, OH, OW, K, device=DEV).to(torch.bfloat16)
+        dw = torch.empty(K, C, 4, 4, device=DEV)
+        ops.wgrad4x4s2(x, dz, dw)
+        ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2).cpu(), (K, C, 4, 4),
+                                          dz.float().permute(0, 3, 1, 2).cpu(), stride=2, padding=1)
+        close(dw, ref.numpy(), 1e-4)
