@@ -206,9 +206,17 @@ size_t sf_transformer_save_floats(int T, int D, int F);
 int sf_transformer_layer_fwd(const float* x, float* y, const float* const* w, float* save, int B,
                              int T, int D, int F, int nhead, float p_drop,
                              unsigned long long seed, void* stream);
-/* x: the layer's forward input; dw: 12 f32 gradient tensors (accumulated with atomics; caller zeroes) */
+/* Offset (floats per sample) of saved array `which` (0 qkv [T,3D], 1 probs [8,T,T], 2 ctx [T,D],
+ * 3 xhat1, 4 rstd1 [8], 5 x1 [T,D], 6 hidden [T,F], 7 xhat2, 8 rstd2): array a of sample b starts at
+ * save + B*offset_a + b*size_a, so each array is one contiguous [B*T, width] matrix. */
+int sf_transformer_save_offset(int T, int D, int F, int which);
+/* x: the layer's forward input.  dw: 12 f32 gradient tensors; only the VECTOR entries (biases,
+ * LayerNorm weights: indices 1,3,5,7,8,9,10,11) are accumulated here (atomics; caller zeroes).
+ * gtok (B*T*(5D+F) floats) receives the per-token gradients g_qkv [B*T,3D], g_sa [B*T,D],
+ * g_z [B*T,F], g_ff [B*T,D], which the caller contracts with x, ctx, x1 and hidden over the
+ * B*T tokens (sf_gemm, both operands reduction-major) to obtain the four weight-matrix gradients. */
 int sf_transformer_layer_bwd(const float* x, const float* dy, float* dx, const float* const* w, float* const* dw,
-                             const float* save, int B, int T, int D, int F, int nhead,
+                             const float* save, float* gtok, int B, int T, int D, int F, int nhead,
                              float p_drop, unsigned long long seed, void* stream);
 /* x[B,T,D] + pe[T,D] (fwd) ; mean over T -> [B,D] (src/model/transformer_module.py:112,118) */
 int sf_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, void* stream);

@@ -87,13 +87,21 @@ __global__ void dconv1_fwd_kernel(const float* __restrict__ x, const float* __re
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = sw[16 * K + cg * EPC + e];
+        // all 16 taps are loaded first (clamped address, masked value) so the loads pipeline
+        float xv[16];
+        const float* xin = x + n * H * (long long)W;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int iy = oh * 2 - 1 + (t >> 2), ix = ow * 2 - 1 + (t & 3);
-            float xv = 0.f;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) xv = x[(n * H + iy) * W + ix];
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            const float v = xin[cy * W + cx];
+            xv[t] = ok ? v : 0.f;
+        }
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[e] += xv * sw[t * K + cg * EPC + e];
+        for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += xv[t] * sw[t * K + cg * EPC + e];
         }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.2f * acc[e];
@@ -101,6 +109,9 @@ __global__ void dconv1_fwd_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
+// one input pixel per group of G lanes (G = K / chunk, a power of two <= 64): each lane handles
+// one 16-byte channel chunk of the (at most four) contributing output pixels, then the group
+// reduces with shuffles.
 template <typename T>
 __global__ void dconv1_bwd_data_kernel(const T* __restrict__ dz, const float* __restrict__ w,
                                        float* __restrict__ dx, int N, int H, int W, int K, int OH, int OW) {
@@ -112,37 +123,44 @@ __global__ void dconv1_bwd_data_kernel(const T* __restrict__ dz, const float* __
     }
     __syncthreads();
     const int G = K / EPC;
+    const int cg = threadIdx.x % G;
+    const long long gid = (blockIdx.x * (long long)NT + threadIdx.x) / G;
+    const long long ngroups = ((long long)gridDim.x * NT) / G;
     const long long total = (long long)N * H * W;
-    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
-        const int ix = (int)(o % W);
-        const long long r = o / W;
-        const int iy = (int)(r % H);
-        const long long n = r / H;
+    const long long rounds = (total + ngroups - 1) / ngroups;
+    for (long long it = 0; it < rounds; ++it) {
+        const long long o = gid + it * ngroups;
+        const bool live = o < total;
         float acc = 0.f;
-        // taps with (iy + 1 - r) even and the quotient inside the output map
+        if (live) {
+            const int ix = (int)(o % W);
+            const long long r = o / W;
+            const int iy = (int)(r % H);
+            const long long n = r / H;
+            // rows r with (iy + 1 - r) even: r = (iy+1)&1 and r + 2; same for columns
+            const int r0 = (iy + 1) & 1, s0 = (ix + 1) & 1;
+            float f[4][EPC];
+            bool ok[4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int ty = iy + 1 - rr;
-            if (ty < 0 || (ty & 1)) continue;
-            const int oh = ty >> 1;
-            if (oh >= OH) continue;
+            for (int q = 0; q < 4; ++q) {
+                const int rr = r0 + 2 * (q >> 1), ss = s0 + 2 * (q & 1);
+                const int oh = (iy + 1 - rr) >> 1, ow = (ix + 1 - ss) >> 1;
+                ok[q] = (iy + 1 - rr) >= 0 && oh < OH && (ix + 1 - ss) >= 0 && ow < OW;
+                const int ch = min(max(oh, 0), OH - 1), cw = min(max(ow, 0), OW - 1);
+                load_chunk<T>(dz + ((n * OH + ch) * OW + cw) * K + cg * EPC, f[q]);
+            }
 #pragma unroll
-            for (int ss = 0; ss < 4; ++ss) {
-                const int tx = ix + 1 - ss;
-                if (tx < 0 || (tx & 1)) continue;
-                const int ow = tx >> 1;
-                if (ow >= OW) continue;
-                const T* src = dz + ((n * OH + oh) * OW + ow) * K;
-                const float* wt = sw + (rr * 4 + ss) * K;
-                for (int cg = 0; cg < G; ++cg) {
-                    float f[EPC];
-                    load_chunk<T>(src + cg * EPC, f);
+            for (int q = 0; q < 4; ++q) {
+                const int rr = r0 + 2 * (q >> 1), ss = s0 + 2 * (q & 1);
+                const float* wt = sw + (rr * 4 + ss) * K + cg * EPC;
+                float a = 0.f;
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc += f[e] * wt[cg * EPC + e];
-                }
+                for (int e = 0; e < EPC; ++e) a += f[q][e] * wt[e];
+                acc += ok[q] ? a : 0.f;
             }
         }
-        dx[o] = acc;
+        for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (live && cg == 0) dx[o] = acc;
     }
 }
 
@@ -167,13 +185,20 @@ __global__ void dconv1_bwd_weight_kernel(const float* __restrict__ x, const T* _
             const long long n = r / OH;
             float f[EPC];
             load_chunk<T>(dz + m * K + cg * EPC, f);
+            float xv[16];
+            const float* xin = x + n * H * (long long)W;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int iy = oh * 2 - 1 + (t >> 2), ix = ow * 2 - 1 + (t & 3);
-                float xv = 0.f;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) xv = x[(n * H + iy) * W + ix];
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                const float v = xin[cy * W + cx];
+                xv[t] = ok ? v : 0.f;
+            }
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) acc[t * EPC + e] += xv * f[e];
+            for (int t = 0; t < 16; ++t) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[t * EPC + e] += xv[t] * f[e];
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[16 * EPC + e] += f[e];
@@ -347,7 +372,9 @@ extern "C" int sf_dconv1_bwd_data(const void* dz, int dtype, const float* w, flo
     SF_REQUIRE(dz && w && dx, "sf_dconv1_bwd_data: null argument");
     int OH, OW;
     if (int rc = dconv1_dims("sf_dconv1_bwd_data", dtype, N, H, W, K, &OH, &OW)) return rc;
-    const long long total = (long long)N * H * W;
+    const int epc_ = dtype == SF_BF16 ? 8 : 4;
+    SF_REQUIRE(((K / epc_) & (K / epc_ - 1)) == 0 && K / epc_ <= 64, "sf_dconv1_bwd_data: K/chunk must be a power of two <= 64");
+    const long long total = (long long)N * H * W * (K / epc_);
     DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_bwd_data_kernel<T>, dim3(grid_for(total)), dim3(NT),
                                          sizeof(float) * 16 * K, (hipStream_t)stream, (const T*)dz, w, dx, N, H, W, K,
                                          OH, OW));

@@ -38,7 +38,8 @@ __device__ __forceinline__ float dot_row(const float* __restrict__ wrow, const f
     return a;
 }
 
-// save layout (floats per sample)
+// save layout: per-sample sizes and offsets; array a of sample b lives at
+// save + B*off_a + b*size_a, i.e. every array is one contiguous [B*T, width] matrix
 struct TrSave {
     int qkv, probs, ctx, xhat1, rstd1, x1, hd, xhat2, rstd2, total;
     __host__ __device__ TrSave(int T, int D, int F) {
@@ -90,7 +91,17 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
     float* tmp = hd + T * F;        // [T][D]
     const int b = blockIdx.x, tid = threadIdx.x;
     const TrSave L(T, D, F);
-    float* sv = save ? save + (size_t)b * L.total : nullptr;
+    const int B = gridDim.x;
+    float* const sv = save;
+    float* const s_qkv = save ? save + (size_t)B * L.qkv + (size_t)b * T * 3 * D : nullptr;
+    float* const s_probs = save ? save + (size_t)B * L.probs + (size_t)b * 8 * T * T : nullptr;
+    float* const s_ctx = save ? save + (size_t)B * L.ctx + (size_t)b * T * D : nullptr;
+    float* const s_xhat1 = save ? save + (size_t)B * L.xhat1 + (size_t)b * T * D : nullptr;
+    float* const s_rstd1 = save ? save + (size_t)B * L.rstd1 + (size_t)b * MAXT : nullptr;
+    float* const s_x1 = save ? save + (size_t)B * L.x1 + (size_t)b * T * D : nullptr;
+    float* const s_hd = save ? save + (size_t)B * L.hd + (size_t)b * T * F : nullptr;
+    float* const s_xhat2 = save ? save + (size_t)B * L.xhat2 + (size_t)b * T * D : nullptr;
+    float* const s_rstd2 = save ? save + (size_t)B * L.rstd2 + (size_t)b * MAXT : nullptr;
     const int hdm = D / nh;
     const float* Win = W.p[0]; const float* bin = W.p[1]; const float* Wo = W.p[2]; const float* bo = W.p[3];
     const float* W1 = W.p[4]; const float* b1 = W.p[5]; const float* W2 = W.p[6]; const float* b2 = W.p[7];
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
         for (int t = 0; t < T; ++t) {
             const float v = dot_row(Win + (size_t)o * D, xs + t * D, D) + bb;
             qkv[t * 3 * D + o] = v;
-            if (sv) sv[L.qkv + t * 3 * D + o] = v;
+            if (sv) s_qkv[t * 3 * D + o] = v;
         }
     }
     __syncthreads();
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
         const float inv = 1.0f / den;
         for (int s = 0; s < T; ++s) {
             const float pv = row[s] * inv;
-            if (sv) sv[L.probs + i * T + s] = pv;
+            if (sv) s_probs[i * T + s] = pv;
             row[s] = pv * drop_mask(p, seed, b, 0, i * T + s);
         }
     }
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
         float a = 0.f;
         for (int s = 0; s < T; ++s) a += pr[(h * T + t) * T + s] * qkv[s * 3 * D + 2 * D + d];
         ctx[i] = a;
-        if (sv) sv[L.ctx + i] = a;
+        if (sv) s_ctx[i] = a;
     }
     __syncthreads();
     for (int o = tid; o < D; o += NT) {
@@ -145,16 +156,16 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
         }
     }
     __syncthreads();
-    layer_norm_tokens(tmp, W.p[8], W.p[9], x1, sv ? sv + L.xhat1 : nullptr, sv ? sv + L.rstd1 : nullptr, T, D);
+    layer_norm_tokens(tmp, W.p[8], W.p[9], x1, s_xhat1, s_rstd1, T, D);
     __syncthreads();
-    if (sv) for (int i = tid; i < T * D; i += NT) sv[L.x1 + i] = x1[i];
+    if (sv) for (int i = tid; i < T * D; i += NT) s_x1[i] = x1[i];
     for (int f = tid; f < F; f += NT) {
         const float bb = b1[f];
         for (int t = 0; t < T; ++t) {
             float v = dot_row(W1 + (size_t)f * D, x1 + t * D, D) + bb;
             v = v > 0.f ? v * drop_mask(p, seed, b, 2, t * F + f) : 0.f;
             hd[t * F + f] = v;
-            if (sv) sv[L.hd + t * F + f] = v;
+            if (sv) s_hd[t * F + f] = v;
         }
     }
     __syncthreads();
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
         }
     }
     __syncthreads();
-    layer_norm_tokens(tmp, W.p[10], W.p[11], xs, sv ? sv + L.xhat2 : nullptr, sv ? sv + L.rstd2 : nullptr, T, D);
+    layer_norm_tokens(tmp, W.p[10], W.p[11], xs, s_xhat2, s_rstd2, T, D);
     __syncthreads();
     for (int i = tid; i < T * D; i += NT) y[(size_t)b * T * D + i] = xs[i];
 }
@@ -192,20 +203,35 @@ __device__ __forceinline__ void layer_norm_bwd_tokens(const float* g, const floa
     }
 }
 
+// Backward of one encoder layer for one sample.  Gradients of the four weight MATRICES are not
+// formed here: the per-token gradient vectors are written to `gtok` (arrays g_qkv [B,T,3D],
+// g_sa [B,T,D], g_z [B,T,F], g_ff [B,T,D]) and the caller contracts them with the saved
+// activations over all B*T tokens in four small GEMMs.  Bias / LayerNorm gradients (short
+// vectors) are accumulated with atomics.
 __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              float* __restrict__ dx, Ptrs12 W, MPtrs12 G,
-                                                             const float* __restrict__ save, int T, int D, int F,
-                                                             int nh, float p, unsigned long long seed) {
+                                                             const float* __restrict__ save, float* __restrict__ gtok,
+                                                             int T, int D, int F, int nh, float p,
+                                                             unsigned long long seed) {
     extern __shared__ float sm[];
     float* g0 = sm;                 // [T][D]
     float* g1 = g0 + T * D;         // [T][D]
     float* gF = g1 + T * D;         // [T][F]  (also d_ctx)
     float* gq = gF + T * F;         // [T][3D]
     float* gp = gq + T * 3 * D;     // [nh][T][T]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
     const TrSave L(T, D, F);
-    const float* sv = save + (size_t)b * L.total;
-    const float* xin = x + (size_t)b * T * D;
+    const float* s_qkv = save + (size_t)B * L.qkv + (size_t)b * T * 3 * D;
+    const float* s_probs = save + (size_t)B * L.probs + (size_t)b * 8 * T * T;
+    const float* s_xhat1 = save + (size_t)B * L.xhat1 + (size_t)b * T * D;
+    const float* s_rstd1 = save + (size_t)B * L.rstd1 + (size_t)b * MAXT;
+    const float* s_hd = save + (size_t)B * L.hd + (size_t)b * T * F;
+    const float* s_xhat2 = save + (size_t)B * L.xhat2 + (size_t)b * T * D;
+    const float* s_rstd2 = save + (size_t)B * L.rstd2 + (size_t)b * MAXT;
+    float* t_qkv = gtok + (size_t)b * T * 3 * D;
+    float* t_sa = gtok + (size_t)B * T * 3 * D + (size_t)b * T * D;
+    float* t_z = gtok + (size_t)B * T * 4 * D + (size_t)b * T * F;
+    float* t_ff = gtok + (size_t)B * T * (4 * D + F) + (size_t)b * T * D;
     const int hdm = D / nh;
     const float* Win = W.p[0]; const float* Wo = W.p[2]; const float* W1 = W.p[4]; const float* W2 = W.p[6];
 
@@ -214,23 +240,20 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     // ---- LayerNorm 2
     for (int d = tid; d < D; d += NT) {
         float a = 0.f, c = 0.f;
-        for (int t = 0; t < T; ++t) { a += g0[t * D + d] * sv[L.xhat2 + t * D + d]; c += g0[t * D + d]; }
+        for (int t = 0; t < T; ++t) { a += g0[t * D + d] * s_xhat2[t * D + d]; c += g0[t * D + d]; }
         atomicAdd(G.p[10] + d, a);
         atomicAdd(G.p[11] + d, c);
     }
-    layer_norm_bwd_tokens(g0, W.p[10], sv + L.xhat2, sv + L.rstd2, g1, T, D);
+    layer_norm_bwd_tokens(g0, W.p[10], s_xhat2, s_rstd2, g1, T, D);
     __syncthreads();
-    // g1 = grad wrt (x1 + ff); d_ff = g1 * mask2 -> g0
-    for (int i = tid; i < T * D; i += NT) g0[i] = g1[i] * drop_mask(p, seed, b, 3, i);
-    __syncthreads();
-    // linear2: dW2[o][f], db2[o]
-    for (int i = tid; i < D * F; i += NT) {
-        const int f = i % F, o = i / F;
-        float a = 0.f;
-        for (int t = 0; t < T; ++t) a += g0[t * D + o] * sv[L.hd + t * F + f];
-        atomicAdd(G.p[6] + i, a);
+    // g1 = grad wrt (x1 + ff); d_ff = g1 * mask2 -> g0 (and out to the token-gradient buffer)
+    for (int i = tid; i < T * D; i += NT) {
+        const float v = g1[i] * drop_mask(p, seed, b, 3, i);
+        g0[i] = v;
+        t_ff[i] = v;
     }
-    for (int o = tid; o < D; o += NT) {
+    __syncthreads();
+    for (int o = tid; o < D; o += NT) {  // linear2 bias
         float a = 0.f;
         for (int t = 0; t < T; ++t) a += g0[t * D + o];
         atomicAdd(G.p[7] + o, a);
@@ -245,27 +268,20 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += g0[t * D + o] * w;
         }
+        float bsum = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
             if (t < T) {
                 const float keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-                gF[t * F + f] = sv[L.hd + t * F + f] > 0.f ? acc[t] * keep : 0.f;
+                const float v = s_hd[t * F + f] > 0.f ? acc[t] * keep : 0.f;
+                gF[t * F + f] = v;
+                t_z[t * F + f] = v;
+                bsum += v;
             }
+        atomicAdd(G.p[5] + f, bsum);  // linear1 bias
     }
     __syncthreads();
-    // linear1: dW1[f][d], db1[f]; d_x1 += dz . W1
-    for (int i = tid; i < F * D; i += NT) {
-        const int d = i % D, f = i / D;
-        float a = 0.f;
-        for (int t = 0; t < T; ++t) a += gF[t * F + f] * sv[L.x1 + t * D + d];
-        atomicAdd(G.p[4] + i, a);
-    }
-    for (int f = tid; f < F; f += NT) {
-        float a = 0.f;
-        for (int t = 0; t < T; ++t) a += gF[t * F + f];
-        atomicAdd(G.p[5] + f, a);
-    }
-    for (int d = tid; d < D; d += NT) {
+    for (int d = tid; d < D; d += NT) {  // d_x1 += dz . W1
         float acc[MAXT];
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
@@ -281,28 +297,25 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     // ---- LayerNorm 1 (g1 = gradient wrt x1)
     for (int d = tid; d < D; d += NT) {
         float a = 0.f, c = 0.f;
-        for (int t = 0; t < T; ++t) { a += g1[t * D + d] * sv[L.xhat1 + t * D + d]; c += g1[t * D + d]; }
+        for (int t = 0; t < T; ++t) { a += g1[t * D + d] * s_xhat1[t * D + d]; c += g1[t * D + d]; }
         atomicAdd(G.p[8] + d, a);
         atomicAdd(G.p[9] + d, c);
     }
-    layer_norm_bwd_tokens(g1, W.p[8], sv + L.xhat1, sv + L.rstd1, g0, T, D);
+    layer_norm_bwd_tokens(g1, W.p[8], s_xhat1, s_rstd1, g0, T, D);
     __syncthreads();
     // g0 = gradient wrt (x + sa); d_sa = g0 * mask1 -> g1
-    for (int i = tid; i < T * D; i += NT) g1[i] = g0[i] * drop_mask(p, seed, b, 1, i);
-    __syncthreads();
-    // out_proj: dWo[o][j], dbo[o]; d_ctx -> gF[0 : T*D]
-    for (int i = tid; i < D * D; i += NT) {
-        const int j = i % D, o = i / D;
-        float a = 0.f;
-        for (int t = 0; t < T; ++t) a += g1[t * D + o] * sv[L.ctx + t * D + j];
-        atomicAdd(G.p[2] + i, a);
+    for (int i = tid; i < T * D; i += NT) {
+        const float v = g0[i] * drop_mask(p, seed, b, 1, i);
+        g1[i] = v;
+        t_sa[i] = v;
     }
-    for (int o = tid; o < D; o += NT) {
+    __syncthreads();
+    for (int o = tid; o < D; o += NT) {  // out_proj bias
         float a = 0.f;
         for (int t = 0; t < T; ++t) a += g1[t * D + o];
         atomicAdd(G.p[3] + o, a);
     }
-    for (int j = tid; j < D; j += NT) {
+    for (int j = tid; j < D; j += NT) {  // d_ctx -> gF[0 : T*D]
         float acc[MAXT];
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     }
     __syncthreads();
     // ---- attention: d_pused = d_ctx . v
-    const float* qkv = sv + L.qkv;
+    const float* qkv = s_qkv;
     for (int i = tid; i < nh * T * T; i += NT) {
         const int s = i % T, t = (i / T) % T, h = i / (T * T);
         float a = 0.f;
@@ -330,9 +343,9 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
         float dot = 0.f;
         for (int s = 0; s < T; ++s) {
             dp[s] = gp[i * T + s] * drop_mask(p, seed, b, 0, i * T + s);
-            dot += dp[s] * sv[L.probs + i * T + s];
+            dot += dp[s] * s_probs[i * T + s];
         }
-        for (int s = 0; s < T; ++s) gp[i * T + s] = sv[L.probs + i * T + s] * (dp[s] - dot) * scale;
+        for (int s = 0; s < T; ++s) gp[i * T + s] = s_probs[i * T + s] * (dp[s] - dot) * scale;
     }
     __syncthreads();
     for (int i = tid; i < T * D; i += NT) {
@@ -341,27 +354,23 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
         for (int s = 0; s < T; ++s) {
             dq += gp[(h * T + t) * T + s] * qkv[s * 3 * D + D + d];
             dk += gp[(h * T + s) * T + t] * qkv[s * 3 * D + d];
-            const float pu = sv[L.probs + (h * T + s) * T + t] * drop_mask(p, seed, b, 0, (h * T + s) * T + t);
+            const float pu = s_probs[(h * T + s) * T + t] * drop_mask(p, seed, b, 0, (h * T + s) * T + t);
             dv += pu * gF[s * D + d];
         }
         gq[t * 3 * D + d] = dq;
         gq[t * 3 * D + D + d] = dk;
         gq[t * 3 * D + 2 * D + d] = dv;
+        t_qkv[t * 3 * D + d] = dq;
+        t_qkv[t * 3 * D + D + d] = dk;
+        t_qkv[t * 3 * D + 2 * D + d] = dv;
     }
     __syncthreads();
-    // in_proj: dWin[o][d], dbin[o]; dx = g0 + gq . Win
-    for (int i = tid; i < 3 * D * D; i += NT) {
-        const int d = i % D, o = i / D;
-        float a = 0.f;
-        for (int t = 0; t < T; ++t) a += gq[t * 3 * D + o] * xin[t * D + d];
-        atomicAdd(G.p[0] + i, a);
-    }
-    for (int o = tid; o < 3 * D; o += NT) {
+    for (int o = tid; o < 3 * D; o += NT) {  // in_proj bias
         float a = 0.f;
         for (int t = 0; t < T; ++t) a += gq[t * 3 * D + o];
         atomicAdd(G.p[1] + o, a);
     }
-    for (int d = tid; d < D; d += NT) {
+    for (int d = tid; d < D; d += NT) {  // dx = g0 + gq . Win
         float acc[MAXT];
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
@@ -521,6 +530,11 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(const float* __restrict__ 
 }  // namespace
 
 extern "C" size_t sf_transformer_save_floats(int T, int D, int F) { return (size_t)TrSave(T, D, F).total; }
+extern "C" int sf_transformer_save_offset(int T, int D, int F, int which) {
+    const TrSave L(T, D, F);
+    const int offs[9] = {L.qkv, L.probs, L.ctx, L.xhat1, L.rstd1, L.x1, L.hd, L.xhat2, L.rstd2};
+    return (which >= 0 && which < 9) ? offs[which] : -1;
+}
 extern "C" size_t sf_lstm_save_floats(int T, int H, int L) { return (size_t)T * L * 6 * H; }
 
 static int tr_check(const char* who, int B, int T, int D, int F, int nh) {
@@ -547,9 +561,9 @@ extern "C" int sf_transformer_layer_fwd(const float* x, float* y, const float* c
 }
 
 extern "C" int sf_transformer_layer_bwd(const float* x, const float* dy, float* dx, const float* const* w,
-                                        float* const* dw, const float* save, int B, int T, int D, int F, int nhead,
-                                        float p_drop, unsigned long long seed, void* stream) {
-    SF_REQUIRE(x && dy && dx && w && dw && save, "sf_transformer_layer_bwd: null argument");
+                                        float* const* dw, const float* save, float* gtok, int B, int T, int D, int F,
+                                        int nhead, float p_drop, unsigned long long seed, void* stream) {
+    SF_REQUIRE(x && dy && dx && w && dw && save && gtok, "sf_transformer_layer_bwd: null argument");
     if (int rc = tr_check("sf_transformer_layer_bwd", B, T, D, F, nhead)) return rc;
     Ptrs12 W; MPtrs12 G;
     for (int i = 0; i < 12; ++i) {
@@ -558,8 +572,8 @@ extern "C" int sf_transformer_layer_bwd(const float* x, const float* dy, float* 
     }
     const size_t lds = sizeof(float) * ((size_t)T * (2 * D + F + 3 * D) + 8 * T * T);
     SF_REQUIRE(lds <= 64 * 1024, "sf_transformer_layer_bwd: sequence does not fit in LDS");
-    hipLaunchKernelGGL(transformer_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, x, dy, dx, W, G, save, T,
-                       D, F, nhead, p_drop, seed);
+    hipLaunchKernelGGL(transformer_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, x, dy, dx, W, G, save, gtok,
+                       T, D, F, nhead, p_drop, seed);
     SF_LAUNCH_CHECK("sf_transformer_layer_bwd");
     return SF_OK;
 }

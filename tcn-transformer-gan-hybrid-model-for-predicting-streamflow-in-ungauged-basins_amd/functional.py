@@ -199,7 +199,7 @@ class TransformerStackFn(torch.autograd.Function):
         nhead, p_drop, seed, T = ctx.cfg
         L = len(ctx.ws) // 12
         g = ops.mean_t_bwd(dout.contiguous().float(), T)
-        dws = [torch.zeros_like(w) for w in ctx.ws]
+        dws = [torch.zeros_like(w) if w.dim() == 1 else torch.empty_like(w) for w in ctx.ws]
         for l in range(L - 1, -1, -1):
             g = ops.transformer_layer_bwd(ctx.inputs[l], g, ctx.ws[12 * l: 12 * l + 12], dws[12 * l: 12 * l + 12],
                                           ctx.saves[l], nhead, p_drop, seed + 7919 * l)

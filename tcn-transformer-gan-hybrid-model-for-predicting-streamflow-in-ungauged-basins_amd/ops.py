@@ -66,7 +66,7 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_conv3x3", "sf_wgrad3x3"
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
            "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_transformer_save_floats",
-           "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
+           "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
            "sf_bce_logits", "sf_adam", "sf_nan_inf_flag"]
 
@@ -484,14 +484,36 @@ def transformer_layer_fwd(x, ws: List[torch.Tensor], nhead, p_drop, seed, save: 
     return y
 
 
+def transformer_save_offset(T, D, F, which) -> int:
+    return int(lib().sf_transformer_save_offset(T, D, F, which))
+
+
 def transformer_layer_bwd(x, dy, ws, dws, save, nhead, p_drop, seed):
+    """Backward of one encoder layer.  dws: 12 gradient tensors; the vector entries must be zeroed
+    by the caller (accumulated with atomics), the four matrices are overwritten by GEMMs over the
+    B*T tokens (A = per-token gradients, B = saved activations, both reduction-major, exact f32
+    MFMA)."""
     _dev(x, dy, save, *ws, *dws)
     B, T, D = x.shape
     Fd = ws[4].shape[0]
+    n = B * T
     dx = torch.empty_like(x)
-    _check(lib().sf_transformer_layer_bwd(_p(x), _p(dy), _p(dx), _ptr_array(ws), _ptr_array(dws), _p(save), B, T, D, Fd,
-                                          nhead, _c_f(p_drop), ctypes.c_ulonglong(seed), _stream()),
+    gtok = torch.empty(n * (5 * D + Fd), device=x.device, dtype=torch.float32)
+    _check(lib().sf_transformer_layer_bwd(_p(x), _p(dy), _p(dx), _ptr_array(ws), _ptr_array(dws), _p(save), _p(gtok),
+                                          B, T, D, Fd, nhead, _c_f(p_drop), ctypes.c_ulonglong(seed), _stream()),
            "sf_transformer_layer_bwd")
+
+    def saved(which, width):
+        o = B * transformer_save_offset(T, D, Fd, which)
+        return save[o:o + n * width]
+
+    g_qkv, g_sa = gtok[: n * 3 * D], gtok[n * 3 * D: n * 4 * D]
+    g_z, g_ff = gtok[n * 4 * D: n * 4 * D + n * Fd], gtok[n * (4 * D + Fd):]
+    xin = x.reshape(-1)
+    linear_gemm(g_qkv, xin, dws[0], 3 * D, D, n, 3 * D, D, D, True, True, OUT_IJ)
+    linear_gemm(g_sa, saved(2, D), dws[2], D, D, n, D, D, D, True, True, OUT_IJ)
+    linear_gemm(g_z, saved(5, D), dws[4], Fd, D, n, Fd, D, D, True, True, OUT_IJ)
+    linear_gemm(g_ff, saved(6, Fd), dws[6], D, Fd, n, D, Fd, Fd, True, True, OUT_IJ)
     return dx
 
 
