@@ -26,9 +26,6 @@ constexpr int NTW = 512;
 constexpr int SA = 192;  // bytes per dOut row in LDS
 
 template <int TAPS, int STRIDE> struct WCfg;
-template <> struct WCfg<9, 1> {
-    static constexpr int R = 3, TPMAX = 256, PPMAX = 400, SB = 192, TPW = 9, KSPLIT = 2;
-};
 template <> struct WCfg<16, 2> {
     static constexpr int R = 4, TPMAX = 128, PPMAX = 864, SB = 160, TPW = 8, KSPLIT = 1;
 };
@@ -39,7 +36,7 @@ struct WPParams {
     float* ws;
     int N, IH, IW, OH, OW, Kd, Cx;
     int TH, TW, tiles_x, tiles_y, ntiles, tiles_per_slice;
-    int kt_tiles, ct_tiles, K64, C64;
+    int kt_tiles, ct_tiles, K64, C64, nslices;
 };
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_tr_p;
@@ -206,6 +203,206 @@ __global__ __launch_bounds__(NTW, 2) void wgrad_patch_kernel(WPParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 stride 1: tiles go from global memory straight into LDS (global_load_lds_dwordx4), into
+// two buffers, so the loads of the next tile run under the MFMAs of the current one and cost
+// no registers.  LDS image of a buffer: [dOut k-half 0][dOut k-half 1][In c-half 0][In c-half 1],
+// each a dense array of 64-byte rows (32 channels of one pixel).  A transposed read takes four
+// consecutive pixels of one half = 256 contiguous bytes = all 64 banks once; a filter tap is a
+// constant byte offset.  One DMA wave-instruction fills 16 rows: lane l writes chunk l%4 of
+// row l/4 and fetches it from that pixel's address, or from a zero chunk when the pixel is
+// padding or outside the tile (no branch around a load: the compiler would serialise them).
+// Waves = (k half, c half) x (taps 0-4 / taps 5-8); 5 accumulator tiles.
+constexpr int G_TP = 256, G_PP = 384;                // pixels of a tile / of its halo patch (max)
+constexpr int G_DIMG = G_TP * 64, G_XIMG = G_PP * 64;
+constexpr int G_BUF = 2 * G_DIMG + 2 * G_XIMG;       // 81,920 bytes; two buffers = all of LDS
+constexpr int G_NSTEPS = G_TP / 16;
+
+__device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> struct IntC { static constexpr int value = N; };
+
+__global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = wave & 1, cb = (wave >> 1) & 1, grp = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int qq4 = (lane & 15) >> 2, csel = (lane >> 4) & 1, p4 = lane & 3;
+
+    // Slice s takes tiles s, s + nslices, ...: at any moment the workgroups read one band of the
+    // images.  Workgroups of one slice (same tiles, different weight blocks) get ids that are
+    // equal modulo 8, which the dispatcher places on one XCD: shared tiles are L2 hits.
+    const int pairs = p.kt_tiles * p.ct_tiles;
+    int pair, slice;
+    if ((p.nslices & 7) == 0) {
+        const int j = blockIdx.x >> 3;
+        pair = j % pairs;
+        slice = (blockIdx.x & 7) + 8 * (j / pairs);
+    } else {
+        pair = blockIdx.x % pairs;
+        slice = blockIdx.x / pairs;
+    }
+    const int ct = pair % p.ct_tiles, kt = pair / p.ct_tiles;
+    const int PW = p.TW + 2, PH = p.TH + 2;
+    const int PP = PH * PW, TP = p.TH * p.TW;
+
+    // ---- DMA jobs of this wave (tile-invariant part).  Job = 16 rows of one image half.
+    // dOut halves: 16 row groups each, this wave fills half (wave & 1), groups (wave >> 1) + 4 i.
+    constexpr int NDJ = G_TP / 16 / 4, NXJ = G_PP / 16 / 4;
+    const int jhalf = wave & 1, jg0 = wave >> 1;
+    const int jrow = lane >> 2, jcol = jhalf * 32 + (lane & 3) * 8;  // row in the group, channel
+    int d_lyx[NDJ], d_rel[NDJ], x_pyx[NXJ], x_rel[NXJ];
+#pragma unroll
+    for (int i = 0; i < NDJ; ++i) {
+        const int pix = 16 * (jg0 + 4 * i) + jrow;
+        const int ly = pix / p.TW, lx = pix - ly * p.TW;
+        d_lyx[i] = pix < TP ? ((ly << 16) | lx) : -1;
+        d_rel[i] = (ly * p.OW + lx) * p.Kd;
+    }
+#pragma unroll
+    for (int i = 0; i < NXJ; ++i) {
+        const int pp = 16 * (jg0 + 4 * i) + jrow;
+        const int py = pp / PW, px = pp - py * PW;
+        x_pyx[i] = pp < PP ? ((py << 16) | px) : -1;
+        x_rel[i] = (py * p.IW + px) * p.Cx;
+    }
+    const bool d_col_ok = kt * 64 + jcol < p.Kd;
+    const bool x_col_ok = ct * 64 + jcol < p.Cx;
+    const bf16* dcol = p.dout + kt * 64 + jcol;
+    const bf16* xcol = p.x + ct * 64 + jcol;
+    const bf16* zsrc = reinterpret_cast<const bf16*>(&g_zero_chunk);
+    const int lds_d0 = jhalf * G_DIMG + jg0 * 1024;               // + i * 4096 (+ buffer)
+    const int lds_x0 = 2 * G_DIMG + jhalf * G_XIMG + jg0 * 1024;
+
+    auto issue_tile = [&](int tile, char* lbase) {
+        const int txi = tile % p.tiles_x;
+        const int rest = tile / p.tiles_x;
+        const int tyi = rest % p.tiles_y;
+        const int n = rest / p.tiles_y;
+        const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
+        const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+        const bf16* dbase = dcol + (((long long)n * p.OH + oy0) * p.OW + ox0) * p.Kd;
+        const bf16* xbase = xcol + (((long long)n * p.IH + iy0) * p.IW + ix0) * p.Cx;
+#pragma unroll
+        for (int i = 0; i < NDJ; ++i) {
+            const int ly = d_lyx[i] >> 16, lx = d_lyx[i] & 0xffff;
+            const bool ok = d_lyx[i] >= 0 && d_col_ok && oy0 + ly < p.OH && ox0 + lx < p.OW;
+            const bf16* src = ok ? dbase + d_rel[i] : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + lds_d0 + i * 4096), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NXJ; ++i) {
+            const int py = x_pyx[i] >> 16, px = x_pyx[i] & 0xffff;
+            const int gy = iy0 + py, gx = ix0 + px;
+            const bool ok = x_pyx[i] >= 0 && x_col_ok && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW;
+            const bf16* src = ok ? xbase + x_rel[i] : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + lds_x0 + i * 4096), 16, 0, 0);
+        }
+    };
+
+    // taps this wave owns (wave-uniform): 0-4 or 5-8
+    constexpr int TPW = 5, TAPS = 9;
+    const int tap_first = grp * TPW;
+    int toffB[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = tap_first + j;
+        toffB[j] = t < TAPS ? ((t / 3) * PW + (t % 3)) * 64 : 0;
+    }
+    // patch rows (as byte offsets / 16) of the two transposed reads of reduction step s:
+    // tile pixel q = 16 s + 8 h + 4 half + qq4
+    int ppk[G_NSTEPS];
+#pragma unroll
+    for (int s = 0; s < G_NSTEPS; ++s) {
+        const int q0 = 16 * s + 8 * h + qq4, q1 = q0 + 4;
+        const int ly0 = q0 / p.TW, lx0 = q0 - ly0 * p.TW;
+        const int ly1 = q1 / p.TW, lx1 = q1 - ly1 * p.TW;
+        const int pp0 = q0 < TP ? ly0 * PW + lx0 : 0;
+        const int pp1 = q1 < TP ? ly1 * PW + lx1 : 0;
+        ppk[s] = (pp0 * 4) | ((pp1 * 4) << 16);
+    }
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    const int lane_col = csel * 32 + p4 * 8;  // byte offset inside a 64-byte row
+    const int aOff = kb * G_DIMG + (8 * h + qq4) * 64 + lane_col;
+    const int bOff = 2 * G_DIMG + cb * G_XIMG + lane_col;
+
+    // Software pipeline over the flattened (step, tap) sequence: the transposed reads of position
+    // i + 2 are issued before the MFMA of position i, in exactly this order, so every MFMA waits
+    // only for its own operands (a counted lgkmcnt) while later reads stay in flight.
+    auto run_steps = [&](auto ntc, const char* aLane, const char* bBase) {
+        constexpr int NT = decltype(ntc)::value;
+        constexpr int TOT = G_NSTEPS * NT, DEPTH = 2;
+        bf16x8 fa[2], fb[DEPTH + 1];
+        const char* b0[2];
+        const char* b1[2];
+        auto issue = [&](int i) {
+            const int s = i / NT, j = i % NT;
+            if (j == 0) {
+                int pk = ppk[s];
+                asm volatile("" : "+v"(pk));  // keep the address arithmetic inside the loop
+                b0[s & 1] = bBase + ((pk & 0xffff) << 4);
+                b1[s & 1] = bBase + ((pk >> 16) << 4);
+                fa[s & 1] = tr_pair(aLane + s * 1024, aLane + s * 1024 + 256);
+            }
+            fb[i % (DEPTH + 1)] = tr_pair(b0[s & 1] + toffB[j], b1[s & 1] + toffB[j]);
+        };
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) issue(i);
+#pragma unroll
+        for (int i = 0; i < TOT; ++i) {
+            if (i + DEPTH < TOT) issue(i + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[i % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(i / NT) & 1], fb[i % (DEPTH + 1)], acc[i % NT], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // One tile: start the DMA of the next tile into `fill`, run the MFMAs on `cur`.  The two
+    // buffers are handed over as restrict pointers so that the compiler knows the reads of
+    // `cur` cannot touch the DMA's destination (otherwise it drains the DMA before every read).
+    auto tile_body = [&](const char* __restrict__ cur, char* __restrict__ fill, int next_tile) {
+        if (next_tile < p.ntiles) issue_tile(next_tile, fill);
+        if (grp == 0) run_steps(IntC<5>{}, cur + aOff, cur + bOff);
+        else run_steps(IntC<4>{}, cur + aOff, cur + bOff);
+    };
+
+    const int tile_step = p.nslices;
+    if (slice < p.ntiles) issue_tile(slice, smw);
+    for (int tile = slice; tile < p.ntiles; tile += 2 * tile_step) {
+        // the tile's DMA has landed (each wave waits for its own, then the barrier) and every wave
+        // is done reading the other buffer
+        __syncthreads();
+        tile_body(smw, smw + G_BUF, tile + tile_step);
+        if (tile + tile_step >= p.ntiles) break;
+        __syncthreads();
+        tile_body(smw + G_BUF, smw, tile + 2 * tile_step);
+    }
+
+    // ---- slab store: ws[slice][k][t][c]; rows = kout (registers), column = lane
+    float* slab = p.ws + (size_t)slice * p.K64 * TAPS * p.C64;
+    const int c = ct * 64 + cb * 32 + r;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = tap_first + j;
+        if (t >= TAPS) break;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            slab[((size_t)k * TAPS + t) * p.C64 + c] = acc[j][e];
+        }
+    }
+}
+
 // dw[k][c][t] (OIHW f32) = sum_slabs ws[slab][k][t][c]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslabs, int K64,
                                     int C64, int K, int Cin, int taps) {
@@ -263,6 +460,7 @@ int run_wgrad(const void* x, const void* dout, float* dw, float* ws, size_t ws_b
     p.K64 = p.kt_tiles * 64;
     p.C64 = p.ct_tiles * 64;
     const int nslices = slices_for(K, Cin);
+    p.nslices = nslices;
     p.tiles_per_slice = (p.ntiles + nslices - 1) / nslices;
     const size_t lds = (size_t)Cf::TPMAX * SA + (size_t)Cf::PPMAX * Cf::SB;
     static bool attr_set = false;
@@ -285,11 +483,71 @@ int run_wgrad(const void* x, const void* dout, float* dw, float* ws, size_t ws_b
     return SF_OK;
 }
 
+// tile of the DMA kernel: at most G_TP pixels, patch at most G_PP; fewest tiles, then least halo
+void pick_tile_dma(int OH, int OW, int* th, int* tw) {
+    long long best = -1;
+    int bth = 1, btw = 8, bpp = 0;
+    for (int w = 4; w <= G_TP; ++w) {
+        int hh = G_TP / w;
+        if (hh > OH) hh = OH;
+        if (hh < 1) continue;
+        const int pp = (hh + 2) * (w + 2);
+        if (pp > G_PP) continue;
+        const long long tiles = (long long)((OW + w - 1) / w) * ((OH + hh - 1) / hh);
+        if (best < 0 || tiles < best || (tiles == best && pp < bpp)) { best = tiles; bth = hh; btw = w; bpp = pp; }
+    }
+    *th = bth; *tw = btw;
+}
+
+int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, size_t need, int N, int H,
+                   int W, int Cx, int Kd, int K, int Cin, hipStream_t s) {
+    const char* who = "sf_wgrad3x3";
+    if (ws_bytes < need) { sf_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need); return SF_EINVAL; }
+    WPParams p;
+    p.dout = (const bf16*)dout; p.x = (const bf16*)x; p.ws = ws;
+    p.N = N; p.IH = H; p.IW = W; p.OH = H; p.OW = W; p.Kd = Kd; p.Cx = Cx;
+    pick_tile_dma(H, W, &p.TH, &p.TW);
+    p.tiles_x = (W + p.TW - 1) / p.TW;
+    p.tiles_y = (H + p.TH - 1) / p.TH;
+    const long long ntiles = (long long)N * p.tiles_x * p.tiles_y;
+    if (ntiles >= 0x7fffffffLL) { sf_set_error("%s: too many tiles", who); return SF_EINVAL; }
+    // 32-bit element offsets inside a tile
+    if ((long long)(p.TH + 2) * W * Cx >= 0x7fffffffLL || (long long)p.TH * W * Kd >= 0x7fffffffLL) {
+        sf_set_error("%s: image rows too large", who); return SF_EINVAL;
+    }
+    p.ntiles = (int)ntiles;
+    p.kt_tiles = (K + 63) / 64;
+    p.ct_tiles = (Cin + 63) / 64;
+    p.K64 = p.kt_tiles * 64;
+    p.C64 = p.ct_tiles * 64;
+    int nslices = slices_for(K, Cin);
+    if (nslices > p.ntiles) nslices = p.ntiles;
+    p.nslices = nslices;
+    p.tiles_per_slice = 0;
+    const size_t lds = 2 * (size_t)G_BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_dma_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            sf_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", who, lds);
+            return SF_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad3_dma_kernel, dim3((unsigned)(nslices * p.kt_tiles * p.ct_tiles)), dim3(NTW), lds, s, p);
+    const long long total = (long long)K * 9 * Cin;
+    int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, ws, dw, nslices, p.K64, p.C64, K, Cin, 9);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sf_set_error("%s: launch failed: %s", who, hipGetErrorString(e)); return SF_ELAUNCH; }
+    return SF_OK;
+}
+
 }  // namespace
 
 extern "C" size_t sf_wgrad3x3_workspace_bytes(int N, int H, int W, int K, int Cin) {
     (void)N; (void)H; (void)W;
-    return sizeof(float) * (size_t)slices_for(K, Cin) * 2 * ((K + 63) / 64 * 64) * 9 * ((Cin + 63) / 64 * 64);
+    return sizeof(float) * (size_t)slices_for(K, Cin) * ((K + 63) / 64 * 64) * 9 * ((Cin + 63) / 64 * 64);
 }
 
 extern "C" size_t sf_wgrad4x4s2_workspace_bytes(int N, int IH, int IW, int K, int Cin) {
@@ -309,8 +567,8 @@ static int wgrad_common_checks(const char* who, const void* x, const void* dout,
 extern "C" int sf_wgrad3x3(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, int N, int H, int W,
                            int Cx, int Kd, int K, int Cin, void* stream) {
     if (int rc = wgrad_common_checks("sf_wgrad3x3", x, dout, dw, ws, N, H, W, Cx, Kd, K, Cin)) return rc;
-    return run_wgrad<9, 1>(x, dout, dw, ws, ws_bytes, sf_wgrad3x3_workspace_bytes(N, H, W, K, Cin), N, H, W, H, W, Cx,
-                           Kd, K, Cin, (hipStream_t)stream, "sf_wgrad3x3");
+    return run_wgrad3_dma(x, dout, dw, ws, ws_bytes, sf_wgrad3x3_workspace_bytes(N, H, W, K, Cin), N, H, W, Cx, Kd, K,
+                          Cin, (hipStream_t)stream);
 }
 
 extern "C" int sf_wgrad4x4s2(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, int N, int IH,
