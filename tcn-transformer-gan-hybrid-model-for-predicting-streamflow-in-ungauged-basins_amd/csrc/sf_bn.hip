@@ -1,0 +1,650 @@
+// BatchNorm passes over NHWC tensors: batch statistics, bias-gradient sums, BN + activation
+// (+ pooling) forward, and the two-pass BN backward fused with the backward of ReLU + maxpool,
+// ReLU + adaptive average pool or LeakyReLU.  All of them are HBM-bound streams.
+//
+// Thread mapping (every kernel here): a thread owns one 16-byte channel chunk `cg` for the
+// whole kernel (per-channel constants live in registers) and walks rows phase, phase + rpp, ...
+// of the workgroup's contiguous row range.  Rows are processed in batches of U: the U loads
+// are issued back to back and without branches (out-of-range rows read a zero chunk), so a
+// thread keeps U (or 2U, 5U) 16-byte loads in flight.  Index arithmetic is 32-bit.
+// Reductions: f32 inside a batch, f64 across batches, shuffles + LDS inside the workgroup in a
+// fixed order, one hardware f64 atomic per channel and workgroup at the end.
+#include "sf_common.h"
+#include "../../include/sfhip.h"
+
+namespace {
+
+constexpr int BT = 512;           // threads per workgroup
+constexpr int MAX_AXIS = 1024;    // avgpool backward: largest H / W the LDS bin tables hold
+constexpr int MAX_BINS = 256;
+
+__device__ __attribute__((aligned(16))) uint4 g_zero16;  // never written: stays zero
+
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ void decode(const uint4& r, float* f) {
+        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y);
+        f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+    }
+    static __device__ __forceinline__ uint4 encode(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Chunk<bf16> {
+    static constexpr int EPC = 8;
+    static __device__ __forceinline__ void decode(const uint4& r, float* f) {
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint4 encode(const float* f) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+        return *reinterpret_cast<const uint4*>(&v);
+    }
+};
+
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ const void* zsrc() { return &g_zero16; }
+
+struct RowMap {
+    int G, rpp, cg, phase;
+    bool active;
+    __device__ __forceinline__ RowMap(int C, int epc) {
+        G = C / epc;
+        rpp = BT / G;
+        cg = threadIdx.x % G;
+        phase = threadIdx.x / G;
+        active = phase < rpp;
+    }
+};
+
+// Sum of v over the threads of the workgroup that own the same channel chunk; valid in
+// threads tid < G (for chunk tid).  Fixed summation order.
+__device__ __forceinline__ double group_sum(double v, const RowMap& m, double* sm /* BT doubles */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int nrows;
+    if ((m.G & (m.G - 1)) == 0 && m.G < 64) {
+        for (int o = 32; o >= m.G; o >>= 1) v += __shfl_xor(v, o, 64);
+        nrows = BT / 64;
+        __syncthreads();
+        if (lane < m.G) sm[wave * m.G + lane] = v;
+    } else {
+        nrows = m.rpp;
+        __syncthreads();
+        if (m.active) sm[m.phase * m.G + m.cg] = v;
+    }
+    __syncthreads();
+    double t = 0.0;
+    if ((int)threadIdx.x < m.G)
+        for (int i = 0; i < nrows; ++i) t += sm[i * m.G + threadIdx.x];
+    return t;
+}
+
+// ------------------------------------------------------------------------------ column sums
+template <typename T, bool SQ>
+__global__ __launch_bounds__(BT) void colsum_kernel(const T* __restrict__ x, unsigned M, unsigned per, int C,
+                                                    double* __restrict__ ws) {
+    constexpr int EPC = Chunk<T>::EPC, U = 8;
+    const RowMap m(C, EPC);
+    __shared__ double sm[BT];
+    double s[EPC], q[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.0;
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
+    if (m.active) {
+        const T* base = x + m.cg * EPC;
+        for (unsigned r = r0 + m.phase; r < r1; r += m.rpp * U) {
+            uint4 raw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned rr = r + u * m.rpp;
+                raw[u] = ld16(rr < r1 ? (const void*)(base + (size_t)rr * C) : zsrc());
+            }
+            float ps[EPC], pq[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) ps[e] = pq[e] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[EPC];
+                Chunk<T>::decode(raw[u], f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    ps[e] += f[e];
+                    if (SQ) pq[e] += f[e] * f[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s[e] += (double)ps[e];
+                if (SQ) q[e] += (double)pq[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const double ts = group_sum(s[e], m, sm);
+        if ((int)threadIdx.x < m.G) unsafeAtomicAdd(&ws[threadIdx.x * EPC + e], ts);
+        if (SQ) {
+            const double tq = group_sum(q[e], m, sm);
+            if ((int)threadIdx.x < m.G) unsafeAtomicAdd(&ws[C + threadIdx.x * EPC + e], tq);
+        }
+    }
+}
+
+__global__ void ws_to_float_kernel(const double* ws, float* out, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (float)ws[i];
+}
+
+// ------------------------------------------------------------------------------ forward
+// y = maxpool2x2(relu(x*scale+shift)); item = one pooling window
+template <typename T>
+__global__ __launch_bounds__(BT) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, T* __restrict__ y,
+                                                                 unsigned items, unsigned per, int H, int W, int C) {
+    constexpr int EPC = Chunk<T>::EPC, U = 2;
+    const RowMap m(C, EPC);
+    if (!m.active) return;
+    const unsigned PH = H / 2, PW = W / 2;
+    float sc[EPC], sf[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[m.cg * EPC + e]; sf[e] = shift[m.cg * EPC + e]; }
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < items ? r0 + per : items;
+    const T* base = x + m.cg * EPC;
+    for (unsigned r = r0 + m.phase; r < r1; r += m.rpp * U) {
+        uint4 raw[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * m.rpp;
+            const bool ok = rr < r1;
+            const unsigned t = rr / PW, pw = rr - t * PW;
+            const unsigned n = t / PH, ph = t - n * PH;
+            const size_t pix = ((size_t)n * H + 2 * ph) * W + 2 * pw;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                raw[u][k] = ld16(ok ? (const void*)(base + (pix + (k >> 1) * W + (k & 1)) * C) : zsrc());
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * m.rpp;
+            if (rr >= r1) break;
+            float mx[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) mx[e] = 0.f;  // max with 0 == ReLU then max
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float f[EPC];
+                Chunk<T>::decode(raw[u][k], f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float v = f[e] * sc[e] + sf[e];
+                    mx[e] = v > mx[e] ? v : mx[e];
+                }
+            }
+            *reinterpret_cast<uint4*>(y + (size_t)rr * C + m.cg * EPC) = Chunk<T>::encode(mx);
+        }
+    }
+}
+
+// y = leaky_relu(x*scale+shift, 0.2); item = one row
+template <typename T>
+__global__ __launch_bounds__(BT) void bn_lrelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, T* __restrict__ y,
+                                                          unsigned M, unsigned per, int C) {
+    constexpr int EPC = Chunk<T>::EPC, U = 4;
+    const RowMap m(C, EPC);
+    if (!m.active) return;
+    float sc[EPC], sf[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[m.cg * EPC + e]; sf[e] = shift[m.cg * EPC + e]; }
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
+    for (unsigned r = r0 + m.phase; r < r1; r += m.rpp * U) {
+        uint4 raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * m.rpp;
+            raw[u] = ld16(rr < r1 ? (const void*)(x + (size_t)rr * C + m.cg * EPC) : zsrc());
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * m.rpp;
+            if (rr >= r1) break;
+            float f[EPC];
+            Chunk<T>::decode(raw[u], f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float v = f[e] * sc[e] + sf[e];
+                f[e] = v > 0.f ? v : 0.2f * v;
+            }
+            *reinterpret_cast<uint4*>(y + (size_t)rr * C + m.cg * EPC) = Chunk<T>::encode(f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward
+struct BnBwd {
+    const void* x; const void* dy;
+    const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
+    int N, H, W, C, Creal, OH, OW, training;
+    unsigned items, per;
+};
+
+// adaptive average pool bins (ATen): bin i covers [floor(i*in/out), ceil((i+1)*in/out))
+__device__ __forceinline__ int bin_start(int i, int in, int out) { return (i * in) / out; }
+__device__ __forceinline__ int bin_end(int i, int in, int out) { return ((i + 1) * in + out - 1) / out; }
+
+// LDS tables of the avgpool backward: for every input row / column the range of bins that
+// contain it, and for every bin the reciprocal of its length.
+struct PoolTables {
+    int hb[MAX_AXIS], wb[MAX_AXIS];
+    float ih[MAX_BINS], iw[MAX_BINS];
+};
+
+__device__ __forceinline__ void build_axis(int* tab, float* inv, int in, int out) {
+    for (int i = threadIdx.x; i < out; i += BT) inv[i] = 1.0f / (float)(bin_end(i, in, out) - bin_start(i, in, out));
+    for (int p = threadIdx.x; p < in; p += BT) {
+        int lo = (p * out) / in - 1; if (lo < 0) lo = 0;
+        int hi = ((p + 1) * out + in - 1) / in; if (hi > out - 1) hi = out - 1;
+        while (lo < hi && !(p >= bin_start(lo, in, out) && p < bin_end(lo, in, out))) ++lo;
+        while (hi > lo && !(p >= bin_start(hi, in, out) && p < bin_end(hi, in, out))) --hi;
+        tab[p] = lo | (hi << 16);
+    }
+}
+
+// Per-thread channel constants
+template <int EPC> struct Chan {
+    float sc[EPC], sf[EPC], mu[EPC], is[EPC];
+    __device__ __forceinline__ void load(const BnBwd& a, int cg) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = cg * EPC + e;
+            sc[e] = a.scale[c]; sf[e] = a.shift[c]; mu[e] = a.mean[c]; is[e] = a.invstd[c];
+        }
+    }
+};
+
+// One batch of U items for the backward kernels: loads first, then dz (gradient wrt the BN
+// output) and x per pre-BN pixel.  MODE 0 items are 2x2 pooling windows (4 pixels each, the
+// window grid covers odd trailing rows / columns too), MODE 1 / 2 items are pixels.
+template <typename T, int MODE> struct BwdBatch {
+    static constexpr int EPC = Chunk<T>::EPC;
+    static constexpr int U = MODE == 0 ? 2 : 4;
+    static constexpr int PIX = MODE == 0 ? 4 : 1;
+    float xf[U][PIX][EPC], dz[U][PIX][EPC];
+    unsigned opix[U][PIX];  // pre-BN pixel index (row of x / dx), ~0u when invalid
+
+    __device__ __forceinline__ void run(const BnBwd& a, const RowMap& m, const Chan<EPC>& ch, unsigned r, unsigned r1,
+                                        const PoolTables* tabs) {
+        const T* xb = reinterpret_cast<const T*>(a.x) + m.cg * EPC;
+        const T* gb = reinterpret_cast<const T*>(a.dy) + m.cg * EPC;
+        if constexpr (MODE == 2) {
+            uint4 rx[U], rg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned rr = r + u * m.rpp;
+                const bool ok = rr < r1;
+                opix[u][0] = ok ? rr : ~0u;
+                rx[u] = ld16(ok ? (const void*)(xb + (size_t)rr * a.C) : zsrc());
+                rg[u] = ld16(ok ? (const void*)(gb + (size_t)rr * a.C) : zsrc());
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float g[EPC];
+                Chunk<T>::decode(rx[u], xf[u][0]);
+                Chunk<T>::decode(rg[u], g);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float y = xf[u][0][e] * ch.sc[e] + ch.sf[e];
+                    dz[u][0][e] = y > 0.f ? g[e] : 0.2f * g[e];
+                }
+            }
+        } else if constexpr (MODE == 1) {
+            uint4 rx[U];
+            unsigned nn[U], hh[U], ww[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned rr = r + u * m.rpp;
+                const bool ok = rr < r1;
+                opix[u][0] = ok ? rr : ~0u;
+                const unsigned rc = ok ? rr : r;
+                const unsigned t = rc / (unsigned)a.W;
+                ww[u] = rc - t * a.W;
+                nn[u] = t / (unsigned)a.H;
+                hh[u] = t - nn[u] * a.H;
+                rx[u] = ld16(ok ? (const void*)(xb + (size_t)rr * a.C) : zsrc());
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                Chunk<T>::decode(rx[u], xf[u][0]);
+                float acc[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+                const int hbin = tabs->hb[hh[u]], wbin = tabs->wb[ww[u]];
+                for (int i = hbin & 0xffff; i <= (hbin >> 16); ++i)
+                    for (int j = wbin & 0xffff; j <= (wbin >> 16); ++j) {
+                        float g[EPC];
+                        Chunk<T>::decode(ld16(gb + (((size_t)nn[u] * a.OH + i) * a.OW + j) * a.C), g);
+                        const float wgt = tabs->ih[i] * tabs->iw[j];
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) acc[e] += g[e] * wgt;
+                    }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float y = xf[u][0][e] * ch.sc[e] + ch.sf[e];
+                    dz[u][0][e] = y > 0.f ? acc[e] : 0.f;
+                }
+            }
+        } else {
+            const unsigned WH = (a.H + 1) / 2, WW = (a.W + 1) / 2, PH = a.H / 2, PW = a.W / 2;
+            uint4 rx[U][4], rg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned rr = r + u * m.rpp;
+                const bool ok = rr < r1;
+                const unsigned rc = ok ? rr : r;
+                const unsigned t = rc / WW, pw = rc - t * WW;
+                const unsigned n = t / WH, ph = t - n * WH;
+                const bool pooled = ok && ph < PH && pw < PW;
+                rg[u] = ld16(pooled ? (const void*)(gb + (((size_t)n * PH + ph) * PW + pw) * a.C) : zsrc());
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned h = 2 * ph + (k >> 1), w = 2 * pw + (k & 1);
+                    const bool v = ok && h < (unsigned)a.H && w < (unsigned)a.W;
+                    const unsigned pix = (n * a.H + h) * a.W + w;
+                    opix[u][k] = v ? pix : ~0u;
+                    rx[u][k] = ld16(v ? (const void*)(xb + (size_t)pix * a.C) : zsrc());
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float g[EPC];
+                Chunk<T>::decode(rg[u], g);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Chunk<T>::decode(rx[u][k], xf[u][k]);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    float best = xf[u][0][e] * ch.sc[e] + ch.sf[e];
+                    int arg = 0;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const float v = xf[u][k][e] * ch.sc[e] + ch.sf[e];
+                        if (v > best) { best = v; arg = k; }
+                    }
+                    // ReLU precedes the pool: a window whose maximum is <= 0 passes no gradient.
+                    // g is zero for windows outside the pooled map (odd trailing row / column).
+                    const float gv = best > 0.f ? g[e] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dz[u][k][e] = (k == arg) ? gv : 0.f;
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(BnBwd a, double* __restrict__ ws) {
+    using Batch = BwdBatch<T, MODE>;
+    constexpr int EPC = Batch::EPC, U = Batch::U, PIX = Batch::PIX;
+    const RowMap m(a.C, EPC);
+    __shared__ double sm[BT];
+    PoolTables* tabs = nullptr;
+    if constexpr (MODE == 1) {
+        __shared__ PoolTables tabs_s;
+        tabs = &tabs_s;
+        build_axis(tabs->hb, tabs->ih, a.H, a.OH);
+        build_axis(tabs->wb, tabs->iw, a.W, a.OW);
+        __syncthreads();
+    }
+    double s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.0;
+    const unsigned r0 = blockIdx.x * a.per;
+    const unsigned r1 = r0 + a.per < a.items ? r0 + a.per : a.items;
+    if (m.active) {
+        Chan<EPC> ch;
+        ch.load(a, m.cg);
+        for (unsigned r = r0 + m.phase; r < r1; r += m.rpp * U) {
+            Batch b;
+            b.run(a, m, ch, r, r1, tabs);
+            float p1[EPC], p2[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) p1[e] = p2[e] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < PIX; ++k)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        // invalid pixels carry dz = 0 (zero chunk / zero gradient)
+                        const float d = b.opix[u][k] != ~0u ? b.dz[u][k][e] : 0.f;
+                        p1[e] += d;
+                        p2[e] += d * ((b.xf[u][k][e] - ch.mu[e]) * ch.is[e]);
+                    }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1[e] += (double)p1[e]; s2[e] += (double)p2[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const double t1 = group_sum(s1[e], m, sm);
+        if ((int)threadIdx.x < m.G) unsafeAtomicAdd(&ws[threadIdx.x * EPC + e], t1);
+        const double t2 = group_sum(s2[e], m, sm);
+        if ((int)threadIdx.x < m.G) unsafeAtomicAdd(&ws[a.C + threadIdx.x * EPC + e], t2);
+    }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(BT) void bn_bwd_apply_kernel(BnBwd a, const double* __restrict__ ws, T* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    using Batch = BwdBatch<T, MODE>;
+    constexpr int EPC = Batch::EPC, U = Batch::U, PIX = Batch::PIX;
+    const RowMap m(a.C, EPC);
+    PoolTables* tabs = nullptr;
+    if constexpr (MODE == 1) {
+        __shared__ PoolTables tabs_s;
+        tabs = &tabs_s;
+        build_axis(tabs->hb, tabs->ih, a.H, a.OH);
+        build_axis(tabs->wb, tabs->iw, a.W, a.OW);
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < a.Creal; c += BT) {
+            if (dgamma) dgamma[c] = (float)ws[a.C + c];
+            if (dbeta) dbeta[c] = (float)ws[c];
+        }
+    }
+    if (!m.active) return;
+    Chan<EPC> ch;
+    ch.load(a, m.cg);
+    float m1[EPC], m2[EPC];
+    const double inv_m = 1.0 / ((double)a.N * a.H * a.W);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = m.cg * EPC + e;
+        m1[e] = a.training ? (float)(ws[c] * inv_m) : 0.f;
+        m2[e] = a.training ? (float)(ws[a.C + c] * inv_m) : 0.f;
+    }
+    const unsigned r0 = blockIdx.x * a.per;
+    const unsigned r1 = r0 + a.per < a.items ? r0 + a.per : a.items;
+    for (unsigned r = r0 + m.phase; r < r1; r += m.rpp * U) {
+        Batch b;
+        b.run(a, m, ch, r, r1, tabs);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                if (b.opix[u][k] == ~0u) continue;
+                float out[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float xh = (b.xf[u][k][e] - ch.mu[e]) * ch.is[e];
+                    out[e] = ch.sc[e] * (b.dz[u][k][e] - m1[e] - xh * m2[e]);
+                }
+                *reinterpret_cast<uint4*>(dx + (size_t)b.opix[u][k] * a.C + m.cg * EPC) = Chunk<T>::encode(out);
+            }
+    }
+}
+
+// rows per workgroup for `items` rows on at most `cap` workgroups, a multiple of `step`
+struct Split { unsigned per; int grid; };
+inline Split split_rows(long long items, int step, int cap) {
+    long long grid = (items + step - 1) / step;
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    long long per = (items + grid - 1) / grid;
+    per = (per + step - 1) / step * step;
+    grid = (items + per - 1) / per;
+    Split s;
+    s.per = (unsigned)per;
+    s.grid = (int)grid;
+    return s;
+}
+
+int check_chunked(const char* who, int dtype, int C) {
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    if (C <= 0 || C % epc != 0) {
+        sf_set_error("%s: channel count %d must be a positive multiple of %d", who, C, epc);
+        return SF_EINVAL;
+    }
+    if (C / epc > BT) {
+        sf_set_error("%s: channel count %d too wide", who, C);
+        return SF_EINVAL;
+    }
+    return SF_OK;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                       \
+    if ((dtype) == SF_BF16) { using T = bf16; CALL; }                 \
+    else if ((dtype) == SF_F32) { using T = float; CALL; }            \
+    else { sf_set_error("bad dtype %d", (int)(dtype)); return SF_EINVAL; }
+
+static int colsum_launch(const char* who, bool sq, const void* x, int dtype, long long M, int C, double* ws,
+                         hipStream_t s) {
+    SF_REQUIRE(M < 0x7fffffffLL, "%s: too many rows", who);
+    if (hipMemsetAsync(ws, 0, sizeof(double) * (sq ? 2 : 1) * C, s) != hipSuccess) {
+        sf_set_error("%s: memset failed", who);
+        return SF_ELAUNCH;
+    }
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const int rpp = BT / (C / epc);
+    const Split sp = split_rows(M, rpp * 8, 512);
+    if (sq) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, true>), dim3(sp.grid), dim3(BT), 0, s, (const T*)x,
+                                             (unsigned)M, sp.per, C, ws));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, false>), dim3(sp.grid), dim3(BT), 0, s, (const T*)x,
+                                             (unsigned)M, sp.per, C, ws));
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_bn_stats(const void* x, int dtype, long long M, int C, double* ws, void* stream) {
+    SF_REQUIRE(x && ws && M > 0, "sf_bn_stats: bad arguments");
+    if (int rc = check_chunked("sf_bn_stats", dtype, C)) return rc;
+    if (int rc = colsum_launch("sf_bn_stats", true, x, dtype, M, C, ws, (hipStream_t)stream)) return rc;
+    SF_LAUNCH_CHECK("sf_bn_stats");
+    return SF_OK;
+}
+
+extern "C" int sf_channel_sum(const void* x, int dtype, long long M, int C, int Creal, float* out, double* ws,
+                              void* stream) {
+    SF_REQUIRE(x && out && ws && M > 0 && Creal <= C, "sf_channel_sum: bad arguments");
+    if (int rc = check_chunked("sf_channel_sum", dtype, C)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = colsum_launch("sf_channel_sum", false, x, dtype, M, C, ws, s)) return rc;
+    hipLaunchKernelGGL(ws_to_float_kernel, dim3(1), dim3(256), 0, s, ws, out, Creal);
+    SF_LAUNCH_CHECK("sf_channel_sum");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_relu_maxpool_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
+                                      int N, int H, int W, int C, void* stream) {
+    SF_REQUIRE(x && y && scale && shift && N > 0 && H >= 2 && W >= 2, "sf_bn_relu_maxpool_fwd: bad arguments");
+    if (int rc = check_chunked("sf_bn_relu_maxpool_fwd", dtype, C)) return rc;
+    SF_REQUIRE((long long)N * H * W < 0x7fffffffLL, "sf_bn_relu_maxpool_fwd: too many pixels");
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const long long items = (long long)N * (H / 2) * (W / 2);
+    const Split sp = split_rows(items, (BT / (C / epc)) * 2, 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<T>, dim3(sp.grid), dim3(BT), 0, (hipStream_t)stream,
+                                         (const T*)x, scale, shift, (T*)y, (unsigned)items, sp.per, H, W, C));
+    SF_LAUNCH_CHECK("sf_bn_relu_maxpool_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_lrelu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
+                               long long M, int C, void* stream) {
+    SF_REQUIRE(x && y && scale && shift && M > 0 && M < 0x7fffffffLL, "sf_bn_lrelu_fwd: bad arguments");
+    if (int rc = check_chunked("sf_bn_lrelu_fwd", dtype, C)) return rc;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const Split sp = split_rows(M, (BT / (C / epc)) * 4, 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_lrelu_fwd_kernel<T>, dim3(sp.grid), dim3(BT), 0, (hipStream_t)stream,
+                                         (const T*)x, scale, shift, (T*)y, (unsigned)M, sp.per, C));
+    SF_LAUNCH_CHECK("sf_bn_lrelu_fwd");
+    return SF_OK;
+}
+
+static int fill_bnbwd(BnBwd& a, int mode, const void* x, const void* dy, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, const float* gamma, int N, int H, int W, int C,
+                      int Creal, int OH, int OW, int training, int dtype, int dy_dtype, int cap) {
+    SF_REQUIRE(mode >= 0 && mode <= 2, "bn_bwd: bad mode %d", mode);
+    SF_REQUIRE(x && dy && scale && shift && mean && invstd, "bn_bwd: null argument");
+    SF_REQUIRE(dy_dtype == dtype, "bn_bwd: dy dtype must equal x dtype");
+    SF_REQUIRE(N > 0 && H > 0 && W > 0 && Creal <= C, "bn_bwd: bad shape");
+    SF_REQUIRE((long long)N * H * W < 0x7fffffffLL, "bn_bwd: too many pixels");
+    if (mode == 1) {
+        SF_REQUIRE(OH > 0 && OW > 0, "bn_bwd: avgpool mode needs OH, OW");
+        SF_REQUIRE(H <= MAX_AXIS && W <= MAX_AXIS && OH <= MAX_BINS && OW <= MAX_BINS,
+                   "bn_bwd: avgpool mode handles maps up to %d x %d and %d x %d bins", MAX_AXIS, MAX_AXIS, MAX_BINS, MAX_BINS);
+    }
+    if (int rc = check_chunked("bn_bwd", dtype, C)) return rc;
+    a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.Creal = Creal; a.OH = OH; a.OW = OW; a.training = training;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const long long items = mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
+    const Split sp = split_rows(items, (BT / (C / epc)) * (mode == 0 ? 2 : 4), cap);
+    a.items = (unsigned)items;
+    a.per = sp.per;
+    return sp.grid;
+}
+
+extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* dy, int dy_dtype, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, double* ws, int N, int H,
+                                int W, int C, int Creal, int OH, int OW, void* stream) {
+    BnBwd a;
+    const int grid = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, scale, N, H, W, C, Creal, OH, OW, 1, dtype,
+                                dy_dtype, 512);
+    if (grid < 0) return grid;
+    SF_REQUIRE(ws, "sf_bn_bwd_reduce: null workspace");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { sf_set_error("sf_bn_bwd_reduce: memset failed"); return SF_ELAUNCH; }
+#define RED(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), dim3(grid), dim3(BT), 0, s, a, ws))
+    if (mode == 0) { RED(0); } else if (mode == 1) { RED(1); } else { RED(2); }
+#undef RED
+    SF_LAUNCH_CHECK("sf_bn_bwd_reduce");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* dy, int dy_dtype, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* gamma,
+                               const double* ws, int training, void* dx, float* dgamma, float* dbeta, int N, int H,
+                               int W, int C, int Creal, int OH, int OW, void* stream) {
+    BnBwd a;
+    const int grid = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, gamma ? gamma : scale, N, H, W, C, Creal, OH,
+                                OW, training, dtype, dy_dtype, 4096);
+    if (grid < 0) return grid;
+    SF_REQUIRE(ws && dx, "sf_bn_bwd_apply: null argument");
+    hipStream_t s = (hipStream_t)stream;
+#define APP(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MODE>), dim3(grid), dim3(BT), 0, s, a, ws, (T*)dx, dgamma, dbeta))
+    if (mode == 0) { APP(0); } else if (mode == 1) { APP(1); } else { APP(2); }
+#undef APP
+    SF_LAUNCH_CHECK("sf_bn_bwd_apply");
+    return SF_OK;
+}

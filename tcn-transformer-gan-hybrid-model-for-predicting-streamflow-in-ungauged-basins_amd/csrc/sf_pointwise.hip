@@ -1,5 +1,5 @@
-// HBM-bound passes: layout changes, weight packing, BatchNorm statistics / apply / backward
-// fused with ReLU + pooling or LeakyReLU, bias-gradient sums, bilinear resize.
+// HBM-bound passes: layout changes, weight packing, BatchNorm finalisation, BN + ReLU + adaptive
+// average pool forward, bilinear resize.
 // Every kernel moves 16-byte channel chunks of NHWC tensors per lane.
 #include "sf_common.h"
 #include "../../include/sfhip.h"
@@ -92,49 +92,7 @@ template <typename T> __global__ void cast_kernel(const float* __restrict__ in, 
         out[i] = from_f32<T>(in[i]);
 }
 
-// ------------------------------------------------------------------------------ BN statistics
-// thread -> (channel group, row phase); rows strided over the grid; double accumulation.
-template <typename T, bool SQ>
-__global__ void colsum_kernel(const T* __restrict__ x, long long M, int C, double* __restrict__ ws) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    const int G = C / EPC;  // <= NT (checked by the host)
-    const int rpp = NT / G;
-    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
-    const bool active = phase < rpp;
-    __shared__ double sm[NT * 2];
-    double s[EPC], q[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.0;
-    if (active) {
-        for (long long r = (long long)blockIdx.x * rpp + phase; r < M; r += (long long)gridDim.x * rpp) {
-            float f[EPC];
-            load_chunk<T>(x + r * C + cg * EPC, f);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                s[e] += (double)f[e];
-                if (SQ) q[e] += (double)f[e] * (double)f[e];
-            }
-        }
-    }
-    // combine the row phases of one channel group through LDS
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        __syncthreads();
-        sm[threadIdx.x] = s[e];
-        sm[NT + threadIdx.x] = q[e];
-        __syncthreads();
-        if (active && phase == 0) {
-            double ts = 0.0, tq = 0.0;
-            for (int ph = 0; ph < rpp; ++ph) {
-                ts += sm[ph * G + cg];
-                tq += sm[NT + ph * G + cg];
-            }
-            atomicAdd(&ws[cg * EPC + e], ts);
-            if (SQ) atomicAdd(&ws[C + cg * EPC + e], tq);
-        }
-    }
-}
-
+// ------------------------------------------------------------------------------ BN finalize
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, long long M, int C, int Creal,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
@@ -165,38 +123,6 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, long long M, i
         shift[c] = beta[c] - mean * sc;
         mean_o[c] = mean;
         invstd_o[c] = inv;
-    }
-}
-
-// ------------------------------------------------------------------------------ BN + ReLU + maxpool forward
-template <typename T>
-__global__ void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
-                                           const float* __restrict__ shift, T* __restrict__ y, int N, int H,
-                                           int W, int C) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    const int G = C / EPC, PH = H / 2, PW = W / 2;
-    const long long total = (long long)N * PH * PW * G;
-    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
-        const int cg = (int)(o % G);
-        long long r = o / G;
-        const int pw = (int)(r % PW); r /= PW;
-        const int ph = (int)(r % PH);
-        const long long n = r / PH;
-        float sc[EPC], sf[EPC], m[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) { sc[e] = scale[cg * EPC + e]; sf[e] = shift[cg * EPC + e]; m[e] = 0.f; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int h = ph * 2 + (k >> 1), w = pw * 2 + (k & 1);
-            float f[EPC];
-            load_chunk<T>(x + ((n * H + h) * W + w) * C + cg * EPC, f);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float v = f[e] * sc[e] + sf[e];
-                m[e] = v > m[e] ? v : m[e];  // max with 0 == ReLU then max
-            }
-        }
-        store_chunk<T>(y + ((n * PH + ph) * PW + pw) * C + cg * EPC, m);
     }
 }
 
@@ -244,263 +170,6 @@ __global__ void bn_relu_avgpool_fwd_kernel(const T* __restrict__ x, const float*
         for (int it = threadIdx.x; it < cs * OW; it += NT) {
             const int ow = it % OW, c = it / OW;
             y[(((long long)n * Creal + c0 + c) * OH + oh) * OW + ow] = from_f32<TO>(tile[c * ldt + ow]);
-        }
-    }
-}
-
-template <typename T>
-__global__ void bn_lrelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, T* __restrict__ y, long long M, int C) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    const int G = C / EPC;
-    const long long total = M * G;
-    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
-        const int cg = (int)(o % G);
-        float f[EPC];
-        load_chunk<T>(x + o * EPC, f);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float v = f[e] * scale[cg * EPC + e] + shift[cg * EPC + e];
-            f[e] = v > 0.f ? v : 0.2f * v;
-        }
-        store_chunk<T>(y + o * EPC, f);
-    }
-}
-
-// ------------------------------------------------------------------------------ BN backward
-struct BnBwd {
-    const void* x; const void* dy;
-    const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
-    int N, H, W, C, Creal, OH, OW, training;
-};
-
-// dz (gradient wrt the BN output) for one channel chunk at pre-BN pixel (n,h,w).
-// MODE 1: ReLU + adaptive average pool (dy NHWC [N,OH,OW,C]); MODE 2: LeakyReLU (dy NHWC [N,H,W,C]).
-template <typename T, int MODE>
-__device__ __forceinline__ void dz_at(const BnBwd& a, long long n, int h, int w, int cg, const float* xf,
-                                      float* dz) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    const T* dy = reinterpret_cast<const T*>(a.dy);
-    if (MODE == 2) {
-        float g[EPC];
-        load_chunk<T>(dy + ((n * a.H + h) * a.W + w) * a.C + cg * EPC, g);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float y = xf[e] * a.scale[cg * EPC + e] + a.shift[cg * EPC + e];
-            dz[e] = y > 0.f ? g[e] : 0.2f * g[e];
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) dz[e] = 0.f;
-        int ilo = (h * a.OH) / a.H - 1; if (ilo < 0) ilo = 0;
-        int ihi = ((h + 1) * a.OH + a.H - 1) / a.H; if (ihi > a.OH - 1) ihi = a.OH - 1;
-        int jlo = (w * a.OW) / a.W - 1; if (jlo < 0) jlo = 0;
-        int jhi = ((w + 1) * a.OW + a.W - 1) / a.W; if (jhi > a.OW - 1) jhi = a.OW - 1;
-        for (int i = ilo; i <= ihi; ++i) {
-            const int hs = bin_start(i, a.H, a.OH), he = bin_end(i, a.H, a.OH);
-            if (h < hs || h >= he) continue;
-            for (int j = jlo; j <= jhi; ++j) {
-                const int ws_ = bin_start(j, a.W, a.OW), we = bin_end(j, a.W, a.OW);
-                if (w < ws_ || w >= we) continue;
-                float g[EPC];
-                load_chunk<T>(dy + ((n * a.OH + i) * a.OW + j) * a.C + cg * EPC, g);
-                const float inv = 1.0f / (float)((he - hs) * (we - ws_));
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) dz[e] += g[e] * inv;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float y = xf[e] * a.scale[cg * EPC + e] + a.shift[cg * EPC + e];
-            dz[e] = y > 0.f ? dz[e] : 0.f;
-        }
-    }
-}
-
-// MODE 0 (ReLU + maxpool 2x2): work item = one pooling window; dzk[k][e] for its 4 pixels.
-template <typename T>
-__device__ __forceinline__ void dz_window(const BnBwd& a, long long n, int ph, int pw, int cg,
-                                          float xf[4][ElemTraits<T>::EPC], bool valid[4],
-                                          float dz[4][ElemTraits<T>::EPC]) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    const T* x = reinterpret_cast<const T*>(a.x);
-    const T* dy = reinterpret_cast<const T*>(a.dy);
-    const int PH = a.H / 2, PW = a.W / 2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int h = ph * 2 + (k >> 1), w = pw * 2 + (k & 1);
-        valid[k] = h < a.H && w < a.W;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) { xf[k][e] = 0.f; dz[k][e] = 0.f; }
-        if (valid[k]) load_chunk<T>(x + ((n * a.H + h) * a.W + w) * a.C + cg * EPC, xf[k]);
-    }
-    if (ph < PH && pw < PW) {
-        float g[EPC];
-        load_chunk<T>(dy + ((n * PH + ph) * PW + pw) * a.C + cg * EPC, g);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float sc = a.scale[cg * EPC + e], sf = a.shift[cg * EPC + e];
-            float best = xf[0][e] * sc + sf;
-            int arg = 0;
-#pragma unroll
-            for (int k = 1; k < 4; ++k) {
-                const float v = xf[k][e] * sc + sf;
-                if (v > best) { best = v; arg = k; }
-            }
-            // ReLU precedes the pool: a window whose maximum is <= 0 passes no gradient
-            if (best > 0.f) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dz[k][e] = (k == arg) ? g[e] : 0.f;
-            }
-        }
-    }
-}
-
-template <typename T, int MODE>
-__global__ void bn_bwd_reduce_kernel(BnBwd a, double* __restrict__ ws) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    const int G = a.C / EPC;
-    const int rpp = NT / G > 0 ? NT / G : 1;
-    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
-    const bool active = G <= NT && phase < rpp;
-    const T* x = reinterpret_cast<const T*>(a.x);
-    double s1[EPC], s2[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.0;
-    float mu[EPC], is[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) { mu[e] = a.mean[cg * EPC + e]; is[e] = a.invstd[cg * EPC + e]; }
-    if (active) {
-        if (MODE == 0) {
-            const int WH = (a.H + 1) / 2, WW = (a.W + 1) / 2;
-            const long long items = (long long)a.N * WH * WW;
-            for (long long r = (long long)blockIdx.x * rpp + phase; r < items; r += (long long)gridDim.x * rpp) {
-                const int pw = (int)(r % WW);
-                const long long t = r / WW;
-                const int ph = (int)(t % WH);
-                const long long n = t / WH;
-                float xf[4][EPC], dz[4][EPC];
-                bool valid[4];
-                dz_window<T>(a, n, ph, pw, cg, xf, valid, dz);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        s1[e] += (double)dz[k][e];
-                        s2[e] += (double)(dz[k][e] * ((xf[k][e] - mu[e]) * is[e]));
-                    }
-            }
-        } else {
-            const long long items = (long long)a.N * a.H * a.W;
-            for (long long r = (long long)blockIdx.x * rpp + phase; r < items; r += (long long)gridDim.x * rpp) {
-                const int w = (int)(r % a.W);
-                const long long t = r / a.W;
-                const int h = (int)(t % a.H);
-                const long long n = t / a.H;
-                float xf[EPC], dz[EPC];
-                load_chunk<T>(x + r * a.C + cg * EPC, xf);
-                dz_at<T, MODE>(a, n, h, w, cg, xf, dz);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    s1[e] += (double)dz[e];
-                    s2[e] += (double)(dz[e] * ((xf[e] - mu[e]) * is[e]));
-                }
-            }
-        }
-    }
-    __shared__ double sm[NT * 2];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        __syncthreads();
-        sm[threadIdx.x] = s1[e];
-        sm[NT + threadIdx.x] = s2[e];
-        __syncthreads();
-        if (active && phase == 0) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int ph = 0; ph < rpp; ++ph) { t1 += sm[ph * G + cg]; t2 += sm[NT + ph * G + cg]; }
-            atomicAdd(&ws[cg * EPC + e], t1);
-            atomicAdd(&ws[a.C + cg * EPC + e], t2);
-        }
-    }
-}
-
-// Per-channel-group constants of the BN backward, reloaded only when the group changes (a
-// thread keeps its group across the grid-stride loop whenever the group count divides 256).
-template <int EPC> struct BnChan {
-    int cg = -1;
-    float sc[EPC], mu[EPC], is[EPC], m1[EPC], m2[EPC];
-    __device__ __forceinline__ void load(const BnBwd& a, const double* __restrict__ ws, int g, double inv_m) {
-        if (g == cg) return;
-        cg = g;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const int c = g * EPC + e;
-            sc[e] = a.scale[c]; mu[e] = a.mean[c]; is[e] = a.invstd[c];
-            m1[e] = a.training ? (float)(ws[c] * inv_m) : 0.f;
-            m2[e] = a.training ? (float)(ws[a.C + c] * inv_m) : 0.f;
-        }
-    }
-};
-
-template <typename T, int MODE>
-__global__ void bn_bwd_apply_kernel(BnBwd a, const double* __restrict__ ws, T* __restrict__ dx,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    const int G = a.C / EPC;
-    const T* x = reinterpret_cast<const T*>(a.x);
-    const double inv_m = 1.0 / ((double)a.N * a.H * a.W);
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < a.Creal; c += NT) {
-            if (dgamma) dgamma[c] = (float)ws[a.C + c];
-            if (dbeta) dbeta[c] = (float)ws[c];
-        }
-    }
-    BnChan<EPC> ch;
-    if (MODE == 0) {
-        const int WH = (a.H + 1) / 2, WW = (a.W + 1) / 2;
-        const long long total = (long long)a.N * WH * WW * G;
-        for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
-            const int cg = (int)(o % G);
-            long long r = o / G;
-            const int pw = (int)(r % WW); r /= WW;
-            const int ph = (int)(r % WH);
-            const long long n = r / WH;
-            ch.load(a, ws, cg, inv_m);
-            float xf[4][EPC], dz[4][EPC];
-            bool valid[4];
-            dz_window<T>(a, n, ph, pw, cg, xf, valid, dz);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!valid[k]) continue;
-                const int h = ph * 2 + (k >> 1), w = pw * 2 + (k & 1);
-                float out[EPC];
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const float xh = (xf[k][e] - ch.mu[e]) * ch.is[e];
-                    out[e] = ch.sc[e] * (dz[k][e] - ch.m1[e] - xh * ch.m2[e]);
-                }
-                store_chunk<T>(dx + ((n * a.H + h) * a.W + w) * a.C + cg * EPC, out);
-            }
-        }
-    } else {
-        const long long total = (long long)a.N * a.H * a.W * G;
-        for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
-            const int cg = (int)(o % G);
-            const long long r = o / G;
-            const int w = (int)(r % a.W);
-            const long long t = r / a.W;
-            const int h = (int)(t % a.H);
-            const long long n = t / a.H;
-            ch.load(a, ws, cg, inv_m);
-            float xf[EPC], dz[EPC], out[EPC];
-            load_chunk<T>(x + o * EPC, xf);
-            dz_at<T, MODE>(a, n, h, w, cg, xf, dz);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float xh = (xf[e] - ch.mu[e]) * ch.is[e];
-                out[e] = ch.sc[e] * (dz[e] - ch.m1[e] - xh * ch.m2[e]);
-            }
-            store_chunk<T>(dx + o * EPC, out);
         }
     }
 }
@@ -679,40 +348,6 @@ static int check_chunked(const char* who, int dtype, int C) {
     return SF_OK;
 }
 
-extern "C" int sf_bn_stats(const void* x, int dtype, long long M, int C, double* ws, void* stream) {
-    SF_REQUIRE(x && ws && M > 0, "sf_bn_stats: bad arguments");
-    if (int rc = check_chunked("sf_bn_stats", dtype, C)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { sf_set_error("sf_bn_stats: memset failed"); return SF_ELAUNCH; }
-    const int epc = dtype == SF_BF16 ? 8 : 4;
-    const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
-    int grid = (int)((M + rpp * 8 - 1) / (rpp * 8)); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, true>), dim3(grid), dim3(NT), 0, s, (const T*)x, M, C, ws));
-    SF_LAUNCH_CHECK("sf_bn_stats");
-    return SF_OK;
-}
-
-namespace {
-__global__ void ws_to_float_kernel(const double* ws, float* out, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (float)ws[i];
-}
-}  // namespace
-
-extern "C" int sf_channel_sum(const void* x, int dtype, long long M, int C, int Creal, float* out, double* ws,
-                                 void* stream) {
-    SF_REQUIRE(x && out && ws && M > 0 && Creal <= C, "sf_channel_sum: bad arguments");
-    if (int rc = check_chunked("sf_channel_sum", dtype, C)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * C, s) != hipSuccess) { sf_set_error("sf_channel_sum: memset failed"); return SF_ELAUNCH; }
-    const int epc = dtype == SF_BF16 ? 8 : 4;
-    const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
-    int grid = (int)((M + rpp * 8 - 1) / (rpp * 8)); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, false>), dim3(grid), dim3(NT), 0, s, (const T*)x, M, C, ws));
-    hipLaunchKernelGGL(ws_to_float_kernel, dim3(1), dim3(NT), 0, s, ws, out, Creal);
-    SF_LAUNCH_CHECK("sf_channel_sum");
-    return SF_OK;
-}
-
 extern "C" int sf_bn_finalize(const double* ws, long long M, int C, int Creal, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, int training,
                               float* scale, float* shift, float* mean, float* invstd, void* stream) {
@@ -722,18 +357,6 @@ extern "C" int sf_bn_finalize(const double* ws, long long M, int C, int Creal, c
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, ws, M, C, Creal, gamma, beta,
                        running_mean, running_var, momentum, eps, training, scale, shift, mean, invstd);
     SF_LAUNCH_CHECK("sf_bn_finalize");
-    return SF_OK;
-}
-
-extern "C" int sf_bn_relu_maxpool_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
-                                      int N, int H, int W, int C, void* stream) {
-    SF_REQUIRE(x && y && scale && shift && N > 0 && H >= 2 && W >= 2, "sf_bn_relu_maxpool_fwd: bad arguments");
-    if (int rc = check_chunked("sf_bn_relu_maxpool_fwd", dtype, C)) return rc;
-    const int epc = dtype == SF_BF16 ? 8 : 4;
-    const long long total = (long long)N * (H / 2) * (W / 2) * (C / epc);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<T>, dim3(grid_for(total, 8192)), dim3(NT), 0,
-                                         (hipStream_t)stream, (const T*)x, scale, shift, (T*)y, N, H, W, C));
-    SF_LAUNCH_CHECK("sf_bn_relu_maxpool_fwd");
     return SF_OK;
 }
 
@@ -754,69 +377,6 @@ extern "C" int sf_bn_relu_avgpool_fwd(const void* x, int dtype, const float* sca
         hipLaunchKernelGGL((bn_relu_avgpool_fwd_kernel<float, float>), grid, block, lds, s, (const float*)x, scale, shift, (float*)y, N, H, W, C, Creal, OH, OW);
     else { sf_set_error("sf_bn_relu_avgpool_fwd: unsupported dtype pair %d -> %d", dtype, out_dtype); return SF_EINVAL; }
     SF_LAUNCH_CHECK("sf_bn_relu_avgpool_fwd");
-    return SF_OK;
-}
-
-extern "C" int sf_bn_lrelu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
-                               long long M, int C, void* stream) {
-    SF_REQUIRE(x && y && scale && shift && M > 0, "sf_bn_lrelu_fwd: bad arguments");
-    if (int rc = check_chunked("sf_bn_lrelu_fwd", dtype, C)) return rc;
-    const int epc = dtype == SF_BF16 ? 8 : 4;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_lrelu_fwd_kernel<T>, dim3(grid_for(M * (C / epc), 8192)), dim3(NT), 0,
-                                         (hipStream_t)stream, (const T*)x, scale, shift, (T*)y, M, C));
-    SF_LAUNCH_CHECK("sf_bn_lrelu_fwd");
-    return SF_OK;
-}
-
-static int fill_bnbwd(BnBwd& a, int mode, const void* x, const void* dy, const float* scale, const float* shift,
-                      const float* mean, const float* invstd, const float* gamma, int N, int H, int W, int C,
-                      int Creal, int OH, int OW, int training, int dtype, int dy_dtype) {
-    SF_REQUIRE(mode >= 0 && mode <= 2, "bn_bwd: bad mode %d", mode);
-    SF_REQUIRE(x && dy && scale && shift && mean && invstd, "bn_bwd: null argument");
-    SF_REQUIRE(dy_dtype == dtype, "bn_bwd: dy dtype must equal x dtype");
-    SF_REQUIRE(N > 0 && H > 0 && W > 0 && Creal <= C, "bn_bwd: bad shape");
-    if (mode == 1) SF_REQUIRE(OH > 0 && OW > 0, "bn_bwd: avgpool mode needs OH, OW");
-    const int epc = dtype == SF_BF16 ? 8 : 4;
-    SF_REQUIRE(C % epc == 0 && C / epc <= NT, "bn_bwd: channel count %d unsupported", C);
-    a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
-    a.N = N; a.H = H; a.W = W; a.C = C; a.Creal = Creal; a.OH = OH; a.OW = OW; a.training = training;
-    return SF_OK;
-}
-
-extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* dy, int dy_dtype, const float* scale,
-                                const float* shift, const float* mean, const float* invstd, double* ws, int N, int H,
-                                int W, int C, int Creal, int OH, int OW, void* stream) {
-    BnBwd a;
-    if (int rc = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, scale, N, H, W, C, Creal, OH, OW, 1, dtype, dy_dtype)) return rc;
-    SF_REQUIRE(ws, "sf_bn_bwd_reduce: null workspace");
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { sf_set_error("sf_bn_bwd_reduce: memset failed"); return SF_ELAUNCH; }
-    const int epc = dtype == SF_BF16 ? 8 : 4;
-    const int rpp = NT / (C / epc) > 0 ? NT / (C / epc) : 1;
-    const long long items = mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
-    int grid = (int)((items + rpp * 8 - 1) / (rpp * 8)); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
-#define RED(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), dim3(grid), dim3(NT), 0, s, a, ws))
-    if (mode == 0) { RED(0); } else if (mode == 1) { RED(1); } else { RED(2); }
-#undef RED
-    SF_LAUNCH_CHECK("sf_bn_bwd_reduce");
-    return SF_OK;
-}
-
-extern "C" int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* dy, int dy_dtype, const float* scale,
-                               const float* shift, const float* mean, const float* invstd, const float* gamma,
-                               const double* ws, int training, void* dx, float* dgamma, float* dbeta, int N, int H,
-                               int W, int C, int Creal, int OH, int OW, void* stream) {
-    BnBwd a;
-    if (int rc = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, gamma ? gamma : scale, N, H, W, C, Creal, OH, OW, training, dtype, dy_dtype)) return rc;
-    SF_REQUIRE(ws && dx, "sf_bn_bwd_apply: null argument");
-    hipStream_t s = (hipStream_t)stream;
-    const int epc = dtype == SF_BF16 ? 8 : 4;
-    const long long items = (mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W) * (C / epc);
-    const int grid = grid_for(items, 8192);
-#define APP(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MODE>), dim3(grid), dim3(NT), 0, s, a, ws, (T*)dx, dgamma, dbeta))
-    if (mode == 0) { APP(0); } else if (mode == 1) { APP(1); } else { APP(2); }
-#undef APP
-    SF_LAUNCH_CHECK("sf_bn_bwd_apply");
     return SF_OK;
 }
 
