@@ -56,7 +56,7 @@ __device__ __forceinline__ void reduce_phases_atomic(const float* vals, int G, i
                     float t = 0.f;
                     for (int ph = 0; ph < rpp; ++ph) t += sm[v * NT + ph * G + cg];
                     const long long idx = out_index(cg, v0 + v);
-                    if (idx >= 0) atomicAdd(out + idx, t);
+                    if (idx >= 0) unsafeAtomicAdd(out + idx, t);
                 }
             }
         }
@@ -164,56 +164,71 @@ __global__ void dconv1_bwd_data_kernel(const T* __restrict__ dz, const float* __
     }
 }
 
+// dw[k][t] = sum_m dz[m][k] * x[pixel(m) + tap t], db[k] = sum_m dz[m][k].  A thread owns one
+// 16-byte chunk of output channels and one half of the filter rows (8 taps) for the whole
+// kernel and walks the rows of the workgroup's contiguous range in batches of U (all loads of
+// a batch are issued before its arithmetic, clamped addresses, masked values).
 template <typename T>
-__global__ void dconv1_bwd_weight_kernel(const float* __restrict__ x, const T* __restrict__ dz,
-                                         float* __restrict__ dw, float* __restrict__ db, int N, int H, int W,
-                                         int K, int OH, int OW) {
+__global__ __launch_bounds__(NT) void dconv1_bwd_weight_kernel(const float* __restrict__ x, const T* __restrict__ dz,
+                                                               float* __restrict__ dw, float* __restrict__ db,
+                                                               unsigned M, unsigned per, int H, int W, int K, int OH,
+                                                               int OW) {
     constexpr int EPC = ElemTraits<T>::EPC;
-    constexpr int NV = 17 * EPC;
+    constexpr int U = 4;
+    constexpr int NV = 9 * EPC;  // 8 taps + bias
     __shared__ float sm[8 * NT];
-    const int G = K / EPC, rpp = NT / G;
-    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    const int G = K / EPC, G2 = G * 2, rpp = NT / G2;
+    const int cg = threadIdx.x % G, th = (threadIdx.x / G) & 1, phase = threadIdx.x / G2;
     float acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-    const long long M = (long long)N * OH * OW;
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
     if (phase < rpp) {
-        for (long long m = (long long)blockIdx.x * rpp + phase; m < M; m += (long long)gridDim.x * rpp) {
-            const int ow = (int)(m % OW);
-            const long long r = m / OW;
-            const int oh = (int)(r % OH);
-            const long long n = r / OH;
-            float f[EPC];
-            load_chunk<T>(dz + m * K + cg * EPC, f);
-            float xv[16];
-            const float* xin = x + n * H * (long long)W;
+        for (unsigned r = r0 + phase; r < r1; r += rpp * U) {
+            float f[U][EPC], xv[U][8];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int iy = oh * 2 - 1 + (t >> 2), ix = ow * 2 - 1 + (t & 3);
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-                const float v = xin[cy * W + cx];
-                xv[t] = ok ? v : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const unsigned rr = r + u * rpp;
+                const bool live = rr < r1;
+                const unsigned m = live ? rr : r;
+                const unsigned q = m / (unsigned)OW, ow = m - q * OW;
+                const unsigned n = q / (unsigned)OH, oh = q - n * OH;
+                load_chunk<T>(dz + (size_t)m * K + cg * EPC, f[u]);
+                if (!live) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f[u][e] = 0.f;
+                }
+                const float* xin = x + (size_t)n * H * W;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int iy = (int)oh * 2 - 1 + 2 * th + (t >> 2), ix = (int)ow * 2 - 1 + (t & 3);
+                    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                    const float v = xin[cy * W + cx];
+                    xv[u][t] = ok ? v : 0.f;
+                }
             }
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) acc[t * EPC + e] += xv[t] * f[e];
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[t * EPC + e] += xv[u][t] * f[u][e];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[8 * EPC + e] += f[u][e];
             }
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[16 * EPC + e] += f[e];
         }
     }
-    // value v = t*EPC + e -> dw[(cg*EPC+e)*16 + t]; t == 16 -> db
-    float* outs[1] = {dw};
-    (void)outs;
-    reduce_phases_atomic<NV>(acc, G, rpp, sm, dw, [&](int g, int v) -> long long {
+    // thread = phase * G2 + (th * G + cg): reduce over phases with "groups" of G2
+    reduce_phases_atomic<NV>(acc, G2, rpp, sm, dw, [&](int g, int v) -> long long {
         const int t = v / EPC, e = v % EPC;
-        if (t < 16) return (long long)(g * EPC + e) * 16 + t;
+        const int gcg = g % G, gth = g / G;
+        if (t < 8) return (long long)(gcg * EPC + e) * 16 + gth * 8 + t;
         return -1;
     });
-    reduce_phases_atomic<EPC>(acc + 16 * EPC, G, rpp, sm, db, [&](int g, int v) -> long long {
-        return (long long)g * EPC + v;
+    reduce_phases_atomic<EPC>(acc + 8 * EPC, G2, rpp, sm, db, [&](int g, int v) -> long long {
+        return g < G ? (long long)g * EPC + v : -1;
     });
 }
 
@@ -393,11 +408,16 @@ extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, f
         return SF_ELAUNCH;
     }
     const int epc = dtype == SF_BF16 ? 8 : 4;
-    const int rpp = NT / (K / epc);
+    SF_REQUIRE(NT % (2 * (K / epc)) == 0, "sf_dconv1_bwd_weight: K=%d unsupported", K);
+    const int rpp = NT / (2 * (K / epc));
     const long long M = (long long)N * OH * OW;
-    int grid = (int)((M + rpp * 16 - 1) / (rpp * 16)); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_bwd_weight_kernel<T>, dim3(grid), dim3(NT), 0, s, x, (const T*)dz, dw,
-                                         db, N, H, W, K, OH, OW));
+    SF_REQUIRE(M < 0x7fffffffLL, "sf_dconv1_bwd_weight: too many pixels");
+    const int step = rpp * 4;
+    long long grid = (M + step - 1) / step; if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+    long long per = ((M + grid - 1) / grid + step - 1) / step * step;
+    grid = (M + per - 1) / per;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_bwd_weight_kernel<T>, dim3((unsigned)grid), dim3(NT), 0, s, x,
+                                         (const T*)dz, dw, db, (unsigned)M, (unsigned)per, H, W, K, OH, OW));
     SF_LAUNCH_CHECK("sf_dconv1_bwd_weight");
     return SF_OK;
 }

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
                     if (atomic) {
                         float* o = reinterpret_cast<float*>(p.out) + off;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) atomicAdd(o + e, v[e]);
+                        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
                     } else {
                         if (p.act == SF_ACT_RELU) {
 #pragma unroll
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const long long off = (i + e) * p.ldo + j;
-                        if (atomic) atomicAdd(o + off, v[e]); else o[off] = v[e];
+                        if (atomic) unsafeAtomicAdd(o + off, v[e]); else o[off] = v[e];
                     }
                 } else {  // SF_OUT_OIHW (always accumulated atomically)
                     float* o = reinterpret_cast<float*>(p.out);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
                     for (int e = 0; e < 4; ++e) {
                         if (i + e >= p.ldo) continue;  // ldo = real output-channel count of the OIHW tensor
                         const long long off = ((i + e) * g.cin_real + cch) * g.RS + g.tap_rs[tap];
-                        atomicAdd(o + off, v[e]);
+                        unsafeAtomicAdd(o + off, v[e]);
                     }
                 }
             }

@@ -80,7 +80,7 @@ __global__ void loss_reduce_kernel(LossArgs a, double* __restrict__ ws, int pixe
         }
         sw = block_sum_256_d(sw, smd);
         sl = block_sum_256_d(sl, smd + 4);
-        if (threadIdx.x == 0) { atomicAdd(&ws[0], sw); atomicAdd(&ws[1], sl); }
+        if (threadIdx.x == 0) { unsafeAtomicAdd(&ws[0], sw); unsafeAtomicAdd(&ws[1], sl); }
     } else {
         const int lane = threadIdx.x & 63;
         const int wave = ((int)blockIdx.x - pixel_blocks) * (NT / 64) + (threadIdx.x >> 6);
@@ -96,7 +96,7 @@ __global__ void loss_reduce_kernel(LossArgs a, double* __restrict__ ws, int pixe
                 tc += 1.0;
             }
         }
-        if (lane == 0 && tc > 0.0) { atomicAdd(&ws[2], tl); atomicAdd(&ws[3], tc); }
+        if (lane == 0 && tc > 0.0) { unsafeAtomicAdd(&ws[2], tl); unsafeAtomicAdd(&ws[3], tc); }
     }
 }
 
@@ -142,7 +142,7 @@ __global__ void loss_station_grad_kernel(LossArgs a, const double* __restrict__ 
         const float g = a.station_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
         const float coef = a.station_weight * g / ((float)n * cnt);
         for (int i = lane; i < n; i += 64)
-            atomicAdd(&dpred[((size_t)b * a.H + y0 + i / ww) * a.W + x0 + i % ww], coef);
+            unsafeAtomicAdd(&dpred[((size_t)b * a.H + y0 + i / ww) * a.W + x0 + i % ww], coef);
     }
 }
 
@@ -159,7 +159,7 @@ __global__ void bce_reduce_kernel(const float* __restrict__ x, long long n, floa
         if (dx) dx[i] = (1.0f / (1.0f + expf(-v)) - label) * inv_n;
     }
     s = block_sum_256_d(s, smd);
-    if (threadIdx.x == 0) atomicAdd(&ws[0], s);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&ws[0], s);
 }
 __global__ void bce_finish_kernel(const double* ws, long long n, float* loss) { loss[0] = (float)(ws[0] / (double)n); }
 

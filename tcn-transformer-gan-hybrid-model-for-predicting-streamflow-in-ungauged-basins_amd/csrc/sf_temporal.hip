@@ -241,8 +241,8 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     for (int d = tid; d < D; d += NT) {
         float a = 0.f, c = 0.f;
         for (int t = 0; t < T; ++t) { a += g0[t * D + d] * s_xhat2[t * D + d]; c += g0[t * D + d]; }
-        atomicAdd(G.p[10] + d, a);
-        atomicAdd(G.p[11] + d, c);
+        unsafeAtomicAdd(G.p[10] + d, a);
+        unsafeAtomicAdd(G.p[11] + d, c);
     }
     layer_norm_bwd_tokens(g0, W.p[10], s_xhat2, s_rstd2, g1, T, D);
     __syncthreads();
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     for (int o = tid; o < D; o += NT) {  // linear2 bias
         float a = 0.f;
         for (int t = 0; t < T; ++t) a += g0[t * D + o];
-        atomicAdd(G.p[7] + o, a);
+        unsafeAtomicAdd(G.p[7] + o, a);
     }
     // d_hidden -> pre-activation gradient (ReLU and dropout share the saved value's sign)
     for (int f = tid; f < F; f += NT) {
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
                 t_z[t * F + f] = v;
                 bsum += v;
             }
-        atomicAdd(G.p[5] + f, bsum);  // linear1 bias
+        unsafeAtomicAdd(G.p[5] + f, bsum);  // linear1 bias
     }
     __syncthreads();
     for (int d = tid; d < D; d += NT) {  // d_x1 += dz . W1
@@ -298,8 +298,8 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     for (int d = tid; d < D; d += NT) {
         float a = 0.f, c = 0.f;
         for (int t = 0; t < T; ++t) { a += g1[t * D + d] * s_xhat1[t * D + d]; c += g1[t * D + d]; }
-        atomicAdd(G.p[8] + d, a);
-        atomicAdd(G.p[9] + d, c);
+        unsafeAtomicAdd(G.p[8] + d, a);
+        unsafeAtomicAdd(G.p[9] + d, c);
     }
     layer_norm_bwd_tokens(g1, W.p[8], s_xhat1, s_rstd1, g0, T, D);
     __syncthreads();
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     for (int o = tid; o < D; o += NT) {  // out_proj bias
         float a = 0.f;
         for (int t = 0; t < T; ++t) a += g1[t * D + o];
-        atomicAdd(G.p[3] + o, a);
+        unsafeAtomicAdd(G.p[3] + o, a);
     }
     for (int j = tid; j < D; j += NT) {  // d_ctx -> gF[0 : T*D]
         float acc[MAXT];
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     for (int o = tid; o < 3 * D; o += NT) {  // in_proj bias
         float a = 0.f;
         for (int t = 0; t < T; ++t) a += gq[t * 3 * D + o];
-        atomicAdd(G.p[1] + o, a);
+        unsafeAtomicAdd(G.p[1] + o, a);
     }
     for (int d = tid; d < D; d += NT) {  // dx = g0 + gq . Win
         float acc[MAXT];
@@ -508,14 +508,14 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(const float* __restrict__ 
                 a += g * xin[t * H + j];
                 if (t > 0) c2 += g * sv[((size_t)l * T + t - 1) * 6 * H + 5 * H + j];
             }
-            atomicAdd(G.p[4 * l] + i, a);
-            atomicAdd(G.p[4 * l + 1] + i, c2);
+            unsafeAtomicAdd(G.p[4 * l] + i, a);
+            unsafeAtomicAdd(G.p[4 * l + 1] + i, c2);
         }
         for (int r = tid; r < 4 * H; r += NT) {
             float a = 0.f;
             for (int t = 0; t < T; ++t) a += dG[t * 4 * H + r];
-            atomicAdd(G.p[4 * l + 2] + r, a);
-            atomicAdd(G.p[4 * l + 3] + r, a);
+            unsafeAtomicAdd(G.p[4 * l + 2] + r, a);
+            unsafeAtomicAdd(G.p[4 * l + 3] + r, a);
         }
         __syncthreads();
         if (l > 0) {
