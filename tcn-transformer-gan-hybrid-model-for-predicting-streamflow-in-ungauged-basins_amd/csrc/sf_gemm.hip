@@ -68,6 +68,7 @@ struct KParams {
     long long I, J, R, lda, ldb, ldo;
     int niters, iters_per_split, nsplit, ni_tiles, nj_tiles;
     int b_gather, out_mode, out_dtype, act, aux_mode, atomic;
+    unsigned long long dy_pack, dx_pack;  // tap offsets + 8, 4 bits per tap
     sf_conv_geom g;
 };
 
@@ -79,6 +80,11 @@ template <typename T, bool ALIGNED> __device__ __forceinline__ void lds_store16(
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
 }
+
+__device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
+
+// tap offset t of a packed table (4 bits per tap, biased by 8): no memory access
+__device__ __forceinline__ int tap_of(unsigned long long pack, int t) { return (int)((pack >> (4 * t)) & 15) - 8; }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, rem = nwg & 7, x = bid & 7, idx = bid >> 3;
@@ -178,65 +184,66 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
 
     uint4 ra[NA], rb[NB];
 
+    // Loads never sit behind a branch (the compiler would make each wait for the previous one):
+    // a chunk that is out of range or zero padding reads the zero chunk instead.
+    const T* zsrc = reinterpret_cast<const T*>(&g_zero_chunk);
     auto load_tiles = [&](int it) {
         const long long r0 = (long long)it * BK;
         // ---- A
 #pragma unroll
         for (int c = 0; c < NA; ++c) {
-            uint4 v = make_uint4(0, 0, 0, 0);
+            const T* src = zsrc;
             if (NA * NTHREADS == A_CHUNKS || tid + c * NTHREADS < A_CHUNKS) {
                 if constexpr (!A_KM) {
                     const long long i = i0 + a_line[c];
                     const long long r = r0 + (long long)a_cc[c] * EPC;
-                    if (i < p.I && r < p.R) v = *reinterpret_cast<const uint4*>(Ag + i * p.lda + r);
+                    src = (i < p.I && r < p.R) ? Ag + i * p.lda + r : zsrc;
                 } else {
                     const long long r = r0 + a_line[c];
                     const long long i = i0 + (long long)a_cc[c] * EPC;
-                    if (r < p.R && i < p.I) v = *reinterpret_cast<const uint4*>(Ag + r * p.lda + i);
+                    src = (r < p.R && i < p.I) ? Ag + r * p.lda + i : zsrc;
                 }
             }
-            ra[c] = v;
+            ra[c] = *reinterpret_cast<const uint4*>(src);
         }
         // ---- B
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
-            uint4 v = make_uint4(0, 0, 0, 0);
+            const T* src = zsrc;
             if constexpr (!B_KM) {
                 const long long r = r0 + (long long)b_cc[c] * EPC;
                 if (!p.b_gather) {
                     const long long j = j0 + b_line[c];
-                    if (j < p.J && r < p.R) v = *reinterpret_cast<const uint4*>(Bg + j * p.ldb + r);
-                } else if (gp_ok[c] && r < p.R) {
+                    src = (j < p.J && r < p.R) ? Bg + j * p.ldb + r : zsrc;
+                } else {
                     int t, cc;
                     if (c_div_bk) {
-                        t = (int)(r0 / g.C);
-                        cc = (int)(r - (long long)t * g.C);
+                        t = (int)((unsigned)r0 / (unsigned)g.C);
+                        cc = (int)r - t * g.C;
                     } else {
-                        t = (int)(r / g.C);
-                        cc = (int)(r - (long long)t * g.C);
+                        t = (int)((unsigned)r / (unsigned)g.C);
+                        cc = (int)r - t * g.C;
                     }
-                    const int iy = gp_a[c] * g.sh + g.dy[t];
-                    const int ix = gp_b[c] * g.sw + g.dx[t];
-                    if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
-                        const long long pix = ((long long)gp_n[c] * g.IH + iy) * g.IW + ix;
-                        v = *reinterpret_cast<const uint4*>(Bg + pix * g.C + cc);
-                    }
+                    const int iy = gp_a[c] * g.sh + tap_of(p.dy_pack, t);
+                    const int ix = gp_b[c] * g.sw + tap_of(p.dx_pack, t);
+                    const bool ok = gp_ok[c] && r < p.R && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                    const long long pix = ((long long)gp_n[c] * g.IH + iy) * g.IW + ix;
+                    src = ok ? Bg + pix * g.C + cc : zsrc;
                 }
             } else {
                 const long long r = r0 + b_line[c];
                 if (!p.b_gather) {
                     const long long j = j0 + (long long)b_cc[c] * EPC;
-                    if (r < p.R && j < p.J) v = *reinterpret_cast<const uint4*>(Bg + r * p.ldb + j);
-                } else if (gp_ok[c] && r < p.R) {
-                    const int iy = gp_a[c] * g.sh + g.dy[gp_t[c]];
-                    const int ix = gp_b[c] * g.sw + g.dx[gp_t[c]];
-                    if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
-                        const long long pix = ((long long)gp_n[c] * g.IH + iy) * g.IW + ix;
-                        v = *reinterpret_cast<const uint4*>(Bg + pix * g.C + gp_c[c]);
-                    }
+                    src = (r < p.R && j < p.J) ? Bg + r * p.ldb + j : zsrc;
+                } else {
+                    const int iy = gp_a[c] * g.sh + tap_of(p.dy_pack, gp_t[c]);
+                    const int ix = gp_b[c] * g.sw + tap_of(p.dx_pack, gp_t[c]);
+                    const bool ok = gp_ok[c] && r < p.R && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                    const long long pix = ((long long)gp_n[c] * g.IH + iy) * g.IW + ix;
+                    src = ok ? Bg + pix * g.C + gp_c[c] : zsrc;
                 }
             }
-            rb[c] = v;
+            rb[c] = *reinterpret_cast<const uint4*>(src);
         }
         if constexpr (B_KM) {
             if (p.b_gather) {
@@ -472,6 +479,14 @@ extern "C" int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, cons
     p.ni_tiles = p.nj_tiles = 0;
     p.b_gather = d->b_gather; p.out_mode = d->out_mode; p.out_dtype = d->out_dtype;
     p.act = d->act; p.aux_mode = d->aux_mode; p.g = d->g;
+    p.dy_pack = p.dx_pack = 0;
+    if (d->b_gather) {
+        for (int t = 0; t < d->g.ntaps; ++t) {
+            SF_REQUIRE(d->g.dy[t] >= -8 && d->g.dy[t] <= 7 && d->g.dx[t] >= -8 && d->g.dx[t] <= 7, "sf_gemm: tap offsets must lie in [-8, 7]");
+            p.dy_pack |= (unsigned long long)(d->g.dy[t] + 8) << (4 * t);
+            p.dx_pack |= (unsigned long long)(d->g.dx[t] + 8) << (4 * t);
+        }
+    }
     // a requested split keeps its accumulate-into-out semantics even when it degenerates to one slice
     p.atomic = (d->nsplit > 1 || d->out_mode == SF_OUT_OIHW) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
