@@ -9,6 +9,7 @@
 // chunk (latency hidden behind compute; a second resident workgroup covers the LDS store
 // burst).  D is kept as [kout][pixel] so a lane stores 4 consecutive channels per access.
 #include "sf_common.h"
+#include <cstdlib>
 #include "../../include/sfhip.h"
 
 namespace {
@@ -27,6 +28,8 @@ struct C3Params {
     int act, aux_mode, out_dtype;
     int dy[9], dx[9];
 };
+
+__device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
 
 template <int KT, int CK>
 __global__ __launch_bounds__(NT3, 2) void conv3x3_kernel(C3Params p) {
@@ -211,6 +214,352 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_kernel(C3Params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Persistent variant for C % 32 == 0.  A workgroup (8 waves) walks a list of work items
+// (512-pixel tile x 64 output channels); per item it runs over the input channels in stages of
+// 32.  A stage = the nine taps' weights [9][64][32] and the halo patch [PP][32] of that channel
+// block, copied from global memory straight into LDS (global_load_lds_dwordx4) into one of two
+// buffers: the copy of stage s+1 -- which may already belong to the next item -- runs under the
+// 144 MFMAs per SIMD of stage s and costs no registers.  Both images are dense arrays of
+// 64-byte rows (32 channels of one pixel / one output channel); the 16-byte slot of a row is
+// XORed with (row >> 2) & 3, applied on the DMA's per-lane source address and again on the
+// ds_read_b128 address, which spreads the 16 rows of a read group over all 64 banks.
+// Items are dealt so that the workgroups of one XCD work on the same few tiles at a time
+// (different output-channel blocks): the shared input patches are L2 hits.
+constexpr int D_TP = 512, D_PP = 640, D_KT = 64, D_NT = 512;
+constexpr int D_WIMG = 9 * D_KT * 64;          // 36,864 bytes
+constexpr int D_PIMG = D_PP * 64;              // 40,960 bytes
+constexpr int D_BUF = D_WIMG + D_PIMG;         // 77,824 bytes; two buffers = 155,648
+constexpr int D_BIAS_MAX = 1024;                // output channels whose bias fits the LDS copy
+constexpr int D_WJOBS = D_WIMG / 1024, D_PJOBS = D_PIMG / 1024;
+constexpr int D_NWJ = (D_WJOBS + 7) / 8, D_NPJ = (D_PJOBS + 7) / 8;
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct C3DParams {
+    const bf16* in;
+    const bf16* w;
+    const float* bias;
+    const bf16* aux;
+    void* out;
+    int N, H, W, C, K, ldo;
+    int TH, TW, tiles_x, tiles_y, ntiles, ktiles, nchunks;
+    int act, aux_mode, out_dtype, dbg;
+    int dy[9], dx[9];
+};
+
+struct ItemPos {
+    int q, chunk;          // item index inside the XCD's list, channel stage
+    int n, y0, x0, k0;     // decoded item
+};
+
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smd[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int PW = p.TW + 2, PP = (p.TH + 2) * PW, TP = p.TH * p.TW;
+
+    // ---- work list of this workgroup
+    const int xcd = blockIdx.x & 7, jblk = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
+    const int xtiles = xcd < p.ntiles ? (p.ntiles - xcd + 7) >> 3 : 0;
+    const int nitems = xtiles * p.ktiles;
+    auto decode = [&](ItemPos& it) {
+        const int m = it.q / p.ktiles, kt = it.q - m * p.ktiles;
+        const int tile = xcd + 8 * m;
+        const int tx = tile % p.tiles_x;
+        const int rest = tile / p.tiles_x;
+        const int ty = rest % p.tiles_y;
+        it.n = rest / p.tiles_y;
+        it.y0 = ty * p.TH; it.x0 = tx * p.TW; it.k0 = kt * D_KT;
+    };
+
+    // ---- DMA jobs (tile-invariant part).  A job fills 16 consecutive 64-byte rows: lane l writes
+    // slot l & 3 of row l >> 2 and fetches the channel chunk (l & 3) ^ ((row >> 2) & 3).
+    const int jrow = lane >> 2, jslot = lane & 3;
+    int w_rel[D_NWJ], w_k[D_NWJ];
+    (void)w_k;
+#pragma unroll
+    for (int i = 0; i < D_NWJ; ++i) {
+        const int row = 16 * (wave + 8 * i) + jrow;          // t * 64 + k
+        const int t = row >> 6, k = row & 63;
+        w_k[i] = k;
+        w_rel[i] = ((k * 9 + t) * p.C + ((jslot ^ ((row >> 2) & 3)) << 3)) * 2;   // bytes
+    }
+    int p_rel[D_NPJ], p_pyx[D_NPJ];
+#pragma unroll
+    for (int i = 0; i < D_NPJ; ++i) {
+        const int row = 16 * (wave + 8 * i) + jrow;          // patch pixel
+        const int py = row / PW, px = row - py * PW;
+        p_pyx[i] = row < PP ? ((py << 16) | px) : -1;
+        p_rel[i] = ((py * p.W + px) * p.C + ((jslot ^ ((row >> 2) & 3)) << 3)) * 2;   // bytes
+    }
+    const bf16* zsrc = reinterpret_cast<const bf16*>(&g_zero_chunk);
+
+    // The copies are buffer loads with an LDS destination: the buffer is the current image (or
+    // the weight rows from k0 on) at channel offset c0, per-lane byte offsets are 32-bit, and an
+    // offset past the end of the buffer writes zeros -- which is how padding pixels and output
+    // channels beyond K are filled (no branch around a load, no pointer select).
+    auto issue_stage = [&](const ItemPos& it, char* buf) {
+        const int c0 = it.chunk * 32;
+        const bf16* wbase = p.w + (size_t)it.k0 * 9 * p.C + c0;
+        const bf16* ibase = p.in + (size_t)it.n * p.H * p.W * p.C + c0;
+        const unsigned wbytes = (unsigned)(((p.K - it.k0) * 9 * p.C - c0) * 2);
+        const unsigned ibytes = (unsigned)((p.H * p.W * p.C - c0) * 2);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)ibase, 0, ibytes, 0x00020000);
+        const int ioff = (((it.y0 - 1) * p.W + it.x0 - 1) * p.C) * 2;
+#pragma unroll
+        for (int i = 0; i < D_NWJ; ++i) {
+            const int job = wave + 8 * i;
+            if (D_WJOBS % 8 == 0 || job < D_WJOBS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(buf + job * 1024), 16, w_rel[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < D_NPJ; ++i) {
+            const int job = wave + 8 * i;
+            if (D_PJOBS % 8 == 0 || job < D_PJOBS) {
+                const int gy = it.y0 - 1 + (p_pyx[i] >> 16), gx = it.x0 - 1 + (p_pyx[i] & 0xffff);
+                const bool ok = p_pyx[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const int voff = ok ? ioff + p_rel[i] : (int)0x80000000;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lptr_t)(buf + D_WIMG + job * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- compute mapping: wave = 64 pixels x 64 output channels (2 x 2 MFMA tiles)
+    int prow[2];           // patch row of the lane's pixel (centre tap)
+    int lyx[2];
+    bool pin[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int q = wave * 64 + c * 32 + r;
+        pin[c] = q < TP;
+        const int qq = pin[c] ? q : 0;
+        const int ly = qq / p.TW, lx = qq - ly * p.TW;
+        prow[c] = (ly + 1) * PW + lx + 1;
+        lyx[c] = (ly << 16) | lx;
+    }
+    // byte offset of the lane's B fragment in the patch image for tap t, reduction step 0
+    // (step 1 is the same offset ^ 32): tile-invariant, so computed once
+    int pa[2][9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int row = prow[c] + p.dy[t] * PW + p.dx[t];
+            pa[c][t] = (row << 6) + ((((row >> 2) & 3) ^ h) << 4);
+        }
+    // weights: row = t*64 + a*32 + r, slot = (h + 2 ks) ^ ((r >> 2) & 3); one lane offset per ks
+    const int aLane0 = r * 64 + ((h ^ ((r >> 2) & 3)) << 4);
+    const int aLane1 = r * 64 + (((h + 2) ^ ((r >> 2) & 3)) << 4);
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+    };
+    zero_acc();
+
+    // One stage: 9 taps x 2 reduction steps, the four fragment reads of position i + 1 issued
+    // before the four MFMAs of position i (pinned order, counted lgkmcnt).
+    auto run_stage = [&](const char* __restrict__ cur) {
+        const char* wl0 = cur + aLane0;
+        const char* wl1 = cur + aLane1;
+        const char* pl = cur + D_WIMG;
+        bf16x8 fa[2][2], fb[2][2];
+        auto issue = [&](int i) {
+            const int t = i >> 1, ks = i & 1, s = i & 1;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                fa[s][a] = *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (t * 64 + a * 32) * 64);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                fb[s][c] = *reinterpret_cast<const bf16x8*>(pl + (pa[c][t] ^ (ks << 5)));
+        };
+        issue(0);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            if (i + 1 < 18) issue(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][a], fb[i & 1][c], acc[a][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Epilogue of an item.  The ReLU-mask loads are issued together and without branches; the
+    // bias comes from LDS (copied there once per workgroup).
+    const float* sbias = reinterpret_cast<const float*>(smd + 2 * D_BUF);
+    auto epilogue = [&](const ItemPos& it) {
+        long long pixoff[2];
+        bool pv[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int gy = it.y0 + (lyx[c] >> 16), gx = it.x0 + (lyx[c] & 0xffff);
+            pv[c] = pin[c] && gy < p.H && gx < p.W;
+            pixoff[c] = pv[c] ? (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo : 0;
+        }
+        uint2 axr[2][2][4];
+        if (p.aux_mode) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int k = it.k0 + a * 32 + 8 * g + 4 * h;
+                        const bf16* src = (pv[c] && k < p.K) ? p.aux + pixoff[c] + k : zsrc;
+                        axr[c][a][g] = *reinterpret_cast<const uint2*>(src);
+                    }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k = it.k0 + a * 32 + 8 * g + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[a][c][4 * g + e];
+                    if (p.bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(sbias + (k < p.K ? k : 0));
+                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    }
+                    if (p.act == SF_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    } else if (p.act == SF_ACT_LRELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                    }
+                    if (p.aux_mode) {
+                        const float neg = p.aux_mode == 1 ? 0.f : 0.2f;
+                        const unsigned u0 = axr[c][a][g].x, u1 = axr[c][a][g].y;
+                        // bf16 > 0  <=>  sign clear and not zero
+                        const bool p0 = !(u0 & 0x8000u) && (u0 & 0x7fffu), p1 = !(u0 & 0x80000000u) && (u0 & 0x7fff0000u);
+                        const bool p2 = !(u1 & 0x8000u) && (u1 & 0x7fffu), p3 = !(u1 & 0x80000000u) && (u1 & 0x7fff0000u);
+                        v[0] = p0 ? v[0] : neg * v[0]; v[1] = p1 ? v[1] : neg * v[1];
+                        v[2] = p2 ? v[2] : neg * v[2]; v[3] = p3 ? v[3] : neg * v[3];
+                    }
+                    if (pv[c] && k < p.K) {
+                        const long long off = pixoff[c] + k;
+                        if (p.out_dtype == SF_F32) {
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + off) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            Vec4<bf16> o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o.set(e, v[e]);
+                            o.store(reinterpret_cast<bf16*>(p.out) + off);
+                        }
+                    }
+                }
+    };
+
+    // ---- stage loop: cur = stage being computed, nxt = stage being copied
+    if (p.bias) {
+        float* sb = reinterpret_cast<float*>(smd + 2 * D_BUF);
+        for (int i = tid; i < D_BIAS_MAX; i += D_NT) sb[i] = i < p.K ? p.bias[i] : 0.f;
+    }
+    ItemPos cur, nxt;
+    cur.q = jblk; cur.chunk = 0;
+    if (cur.q >= nitems) return;
+    decode(cur);
+    issue_stage(cur, smd);
+    nxt = cur;
+    auto advance = [&](ItemPos& it) {
+        if (++it.chunk == p.nchunks) {
+            it.chunk = 0;
+            it.q += nb8;
+            if (it.q < nitems) decode(it);
+        }
+    };
+    advance(nxt);
+    // one step of the pipeline; `cur_buf` holds the landed stage, `fill` takes the next copy
+    auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
+        if (nxt.q < nitems && !(p.dbg & 1)) issue_stage(nxt, fill);
+        if (!(p.dbg & 2)) run_stage(cur_buf);
+        if (cur.chunk == p.nchunks - 1) {
+            if (!(p.dbg & 4)) epilogue(cur);
+            zero_acc();
+        }
+        cur = nxt;
+        advance(nxt);
+    };
+    while (true) {
+        // the stage's copy has landed (own vmcnt, then the barrier) and every wave is done
+        // reading the buffer the next copy goes to
+        __syncthreads();
+        step(smd, smd + D_BUF);
+        if (cur.q >= nitems) break;
+        __syncthreads();
+        step(smd + D_BUF, smd);
+        if (cur.q >= nitems) break;
+    }
+}
+
+// tile of the persistent kernel: at most D_TP pixels, patch at most D_PP; fewest tiles, least halo
+void pick_tile_dma(int H, int W, int* th, int* tw) {
+    long long best = -1;
+    int bth = 1, btw = 8, bpp = 0;
+    for (int w = 4; w <= D_TP; ++w) {
+        int hh = D_TP / w;
+        if (hh > H) hh = H;
+        if (hh < 1) continue;
+        const int pp = (hh + 2) * (w + 2);
+        if (pp > D_PP) continue;
+        const long long tiles = (long long)((W + w - 1) / w) * ((H + hh - 1) / hh);
+        if (best < 0 || tiles < best || (tiles == best && pp < bpp)) { best = tiles; bth = hh; btw = w; bpp = pp; }
+    }
+    *th = bth; *tw = btw;
+}
+
+int launch3_dma(const C3Params& q, hipStream_t s) {
+    C3DParams p;
+    p.in = q.in; p.w = q.w; p.bias = q.bias; p.aux = q.aux; p.out = q.out;
+    p.N = q.N; p.H = q.H; p.W = q.W; p.C = q.C; p.K = q.K; p.ldo = q.ldo;
+    p.act = q.act; p.aux_mode = q.aux_mode; p.out_dtype = q.out_dtype;
+    for (int t = 0; t < 9; ++t) { p.dy[t] = q.dy[t]; p.dx[t] = q.dx[t]; }
+    p.dbg = getenv("SF_C3_DBG") ? atoi(getenv("SF_C3_DBG")) : 0;
+    pick_tile_dma(p.H, p.W, &p.TH, &p.TW);
+    p.tiles_x = (p.W + p.TW - 1) / p.TW;
+    p.tiles_y = (p.H + p.TH - 1) / p.TH;
+    const long long ntiles = (long long)p.N * p.tiles_x * p.tiles_y;
+    if (ntiles >= 0x7fffffffLL / 8) { sf_set_error("sf_conv3x3: too many tiles"); return SF_EINVAL; }
+    if (2LL * p.H * p.W * p.C >= 0x7fffffffLL || 2LL * p.K * 9 * p.C >= 0x7fffffffLL) {
+        sf_set_error("sf_conv3x3: one image or the weights exceed 2 GiB");
+        return SF_EINVAL;
+    }
+    p.ntiles = (int)ntiles;
+    p.ktiles = (p.K + D_KT - 1) / D_KT;
+    p.nchunks = p.C / 32;
+    const size_t lds = 2 * (size_t)D_BUF + sizeof(float) * D_BIAS_MAX;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_dma_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            sf_set_error("sf_conv3x3: cannot raise the dynamic LDS limit to %zu bytes", lds);
+            return SF_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    long long items = ntiles * p.ktiles;
+    long long grid = (items + 7) / 8 * 8;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(conv3_dma_kernel, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
+    SF_LAUNCH_CHECK("sf_conv3x3");
+    return SF_OK;
+}
+
 // tile shape with the fewest tiles (TH*TW <= 256 lanes, patch <= MAX_PP pixels)
 void pick_tile(int H, int W, int* th, int* tw) {
     long long best = -1;
@@ -269,6 +618,7 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
     p.tiles_x = (W + p.TW - 1) / p.TW;
     p.tiles_y = (H + p.TH - 1) / p.TH;
     hipStream_t s = (hipStream_t)stream;
+    if (C % 32 == 0 && K <= D_BIAS_MAX && !getenv("SF_CONV3_OLD")) return launch3_dma(p, s);
     if (K <= 64 && C % 32 == 0) {
         p.ktiles = (K + 63) / 64;
         return launch3<64, 32>(p, s);
