@@ -210,17 +210,15 @@ __global__ __launch_bounds__(NTW, 2) void wgrad_patch_kernel(WPParams p) {
 // each a dense array of 64-byte rows (32 channels of one pixel).  A transposed read takes four
 // consecutive pixels of one half = 256 contiguous bytes = all 64 banks once; a filter tap is a
 // constant byte offset.  One DMA wave-instruction fills 16 rows: lane l writes chunk l%4 of
-// row l/4 and fetches it from that pixel's address, or from a zero chunk when the pixel is
-// padding or outside the tile (no branch around a load: the compiler would serialise them).
+// row l/4 and fetches it from that pixel (buffer load; out-of-range offsets write zeros for
+// padding and pixels outside the tile).
 // Waves = (k half, c half) x (taps 0-4 / taps 5-8); 5 accumulator tiles.
 constexpr int G_TP = 256, G_PP = 384;                // pixels of a tile / of its halo patch (max)
 constexpr int G_DIMG = G_TP * 64, G_XIMG = G_PP * 64;
 constexpr int G_BUF = 2 * G_DIMG + 2 * G_XIMG;       // 81,920 bytes; two buffers = all of LDS
 constexpr int G_NSTEPS = G_TP / 16;
 
-__device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
 
-typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> struct IntC { static constexpr int value = N; };
@@ -261,23 +259,23 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
         const int pix = 16 * (jg0 + 4 * i) + jrow;
         const int ly = pix / p.TW, lx = pix - ly * p.TW;
         d_lyx[i] = pix < TP ? ((ly << 16) | lx) : -1;
-        d_rel[i] = (ly * p.OW + lx) * p.Kd;
+        d_rel[i] = ((ly * p.OW + lx) * p.Kd + kt * 64 + jcol) * 2;   // bytes
     }
 #pragma unroll
     for (int i = 0; i < NXJ; ++i) {
         const int pp = 16 * (jg0 + 4 * i) + jrow;
         const int py = pp / PW, px = pp - py * PW;
         x_pyx[i] = pp < PP ? ((py << 16) | px) : -1;
-        x_rel[i] = (py * p.IW + px) * p.Cx;
+        x_rel[i] = ((py * p.IW + px) * p.Cx + ct * 64 + jcol) * 2;   // bytes
     }
     const bool d_col_ok = kt * 64 + jcol < p.Kd;
     const bool x_col_ok = ct * 64 + jcol < p.Cx;
-    const bf16* dcol = p.dout + kt * 64 + jcol;
-    const bf16* xcol = p.x + ct * 64 + jcol;
-    const bf16* zsrc = reinterpret_cast<const bf16*>(&g_zero_chunk);
     const int lds_d0 = jhalf * G_DIMG + jg0 * 1024;               // + i * 4096 (+ buffer)
     const int lds_x0 = 2 * G_DIMG + jhalf * G_XIMG + jg0 * 1024;
 
+    // The copies are buffer loads with an LDS destination; the buffer is the tile's image, lane
+    // offsets are 32-bit bytes, and an offset past the buffer's end writes zeros (padding,
+    // pixels outside the tile, channels beyond the tensor).
     auto issue_tile = [&](int tile, char* lbase) {
         const int txi = tile % p.tiles_x;
         const int rest = tile / p.tiles_x;
@@ -285,22 +283,26 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
         const int n = rest / p.tiles_y;
         const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
         const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-        const bf16* dbase = dcol + (((long long)n * p.OH + oy0) * p.OW + ox0) * p.Kd;
-        const bf16* xbase = xcol + (((long long)n * p.IH + iy0) * p.IW + ix0) * p.Cx;
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.dout + (size_t)n * p.OH * p.OW * p.Kd), 0, (unsigned)(p.OH * p.OW * p.Kd * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.x + (size_t)n * p.IH * p.IW * p.Cx), 0, (unsigned)(p.IH * p.IW * p.Cx * 2), 0x00020000);
+        const int doff = (oy0 * p.OW + ox0) * p.Kd * 2;
+        const int xoff = (iy0 * p.IW + ix0) * p.Cx * 2;
 #pragma unroll
         for (int i = 0; i < NDJ; ++i) {
             const int ly = d_lyx[i] >> 16, lx = d_lyx[i] & 0xffff;
             const bool ok = d_lyx[i] >= 0 && d_col_ok && oy0 + ly < p.OH && ox0 + lx < p.OW;
-            const bf16* src = ok ? dbase + d_rel[i] : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + lds_d0 + i * 4096), 16, 0, 0);
+            const int voff = ok ? doff + d_rel[i] : (int)0x80000000;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lptr_t)(lbase + lds_d0 + i * 4096), 16, voff, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NXJ; ++i) {
             const int py = x_pyx[i] >> 16, px = x_pyx[i] & 0xffff;
             const int gy = iy0 + py, gx = ix0 + px;
             const bool ok = x_pyx[i] >= 0 && x_col_ok && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW;
-            const bf16* src = ok ? xbase + x_rel[i] : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + lds_x0 + i * 4096), 16, 0, 0);
+            const int voff = ok ? xoff + x_rel[i] : (int)0x80000000;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(lbase + lds_x0 + i * 4096), 16, voff, 0, 0, 0);
         }
     };
 
@@ -512,8 +514,8 @@ int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t
     const long long ntiles = (long long)N * p.tiles_x * p.tiles_y;
     if (ntiles >= 0x7fffffffLL) { sf_set_error("%s: too many tiles", who); return SF_EINVAL; }
     // 32-bit element offsets inside a tile
-    if ((long long)(p.TH + 2) * W * Cx >= 0x7fffffffLL || (long long)p.TH * W * Kd >= 0x7fffffffLL) {
-        sf_set_error("%s: image rows too large", who); return SF_EINVAL;
+    if (2LL * H * W * Cx >= 0x7fffffffLL || 2LL * H * W * Kd >= 0x7fffffffLL) {
+        sf_set_error("%s: one image exceeds 2 GiB", who); return SF_EINVAL;
     }
     p.ntiles = (int)ntiles;
     p.kt_tiles = (K + 63) / 64;
