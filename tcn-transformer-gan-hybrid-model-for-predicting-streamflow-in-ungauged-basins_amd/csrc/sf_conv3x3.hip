@@ -301,29 +301,38 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     // the weight rows from k0 on) at channel offset c0, per-lane byte offsets are 32-bit, and an
     // offset past the end of the buffer writes zeros -- which is how padding pixels and output
     // channels beyond K are filled (no branch around a load, no pointer select).
-    auto issue_stage = [&](const ItemPos& it, char* buf) {
+    struct StageSrc {
+        __amdgpu_buffer_rsrc_t wrs, irs;
+        int ioff, ym1, xm1;
+    };
+    // `live` false (nothing left to copy) makes both buffers empty: the pieces then write zeros
+    // and touch no memory, and the MFMA loop needs no branch around them.
+    auto stage_src = [&](const ItemPos& it, bool live) {
         const int c0 = it.chunk * 32;
         const bf16* wbase = p.w + (size_t)it.k0 * 9 * p.C + c0;
         const bf16* ibase = p.in + (size_t)it.n * p.H * p.W * p.C + c0;
-        const unsigned wbytes = (unsigned)(((p.K - it.k0) * 9 * p.C - c0) * 2);
-        const unsigned ibytes = (unsigned)((p.H * p.W * p.C - c0) * 2);
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wbytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)ibase, 0, ibytes, 0x00020000);
-        const int ioff = (((it.y0 - 1) * p.W + it.x0 - 1) * p.C) * 2;
-#pragma unroll
-        for (int i = 0; i < D_NWJ; ++i) {
-            const int job = wave + 8 * i;
+        const unsigned wbytes = live ? (unsigned)(((p.K - it.k0) * 9 * p.C - c0) * 2) : 0u;
+        const unsigned ibytes = live ? (unsigned)((p.H * p.W * p.C - c0) * 2) : 0u;
+        StageSrc ss;
+        ss.wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wbytes, 0x00020000);
+        ss.irs = __builtin_amdgcn_make_buffer_rsrc((void*)ibase, 0, ibytes, 0x00020000);
+        ss.ym1 = it.y0 - 1; ss.xm1 = it.x0 - 1;
+        ss.ioff = ((ss.ym1 * p.W + ss.xm1) * p.C) * 2;
+        return ss;
+    };
+    // piece j of a stage's copy: j < D_NWJ weights, then the patch
+    auto issue_piece = [&](const StageSrc& ss, char* buf, int j) {
+        if (j < D_NWJ) {
+            const int job = wave + 8 * j;
             if (D_WJOBS % 8 == 0 || job < D_WJOBS)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(buf + job * 1024), 16, w_rel[i], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < D_NPJ; ++i) {
-            const int job = wave + 8 * i;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(buf + job * 1024), 16, w_rel[j], 0, 0, 0);
+        } else {
+            const int i = j - D_NWJ, job = wave + 8 * i;
             if (D_PJOBS % 8 == 0 || job < D_PJOBS) {
-                const int gy = it.y0 - 1 + (p_pyx[i] >> 16), gx = it.x0 - 1 + (p_pyx[i] & 0xffff);
+                const int gy = ss.ym1 + (p_pyx[i] >> 16), gx = ss.xm1 + (p_pyx[i] & 0xffff);
                 const bool ok = p_pyx[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                const int voff = ok ? ioff + p_rel[i] : (int)0x80000000;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lptr_t)(buf + D_WIMG + job * 1024), 16, voff, 0, 0, 0);
+                const int voff = ok ? ss.ioff + p_rel[i] : (int)0x80000000;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.irs, (lptr_t)(buf + D_WIMG + job * 1024), 16, voff, 0, 0, 0);
             }
         }
     };
@@ -368,7 +377,9 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
 
     // One stage: 9 taps x 2 reduction steps, the four fragment reads of position i + 1 issued
     // before the four MFMAs of position i (pinned order, counted lgkmcnt).
-    auto run_stage = [&](const char* __restrict__ cur) {
+    // One copy piece of the next stage is issued per position (an LDS-DMA instruction holds the
+    // issuing wave for ~100 cycles; spread out, the other wave's MFMAs cover it).
+    auto run_stage = [&](const char* __restrict__ cur, char* __restrict__ fill, const StageSrc& ss) {
         const char* wl0 = cur + aLane0;
         const char* wl1 = cur + aLane1;
         const char* pl = cur + D_WIMG;
@@ -386,6 +397,7 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             if (i + 1 < 18) issue(i + 1);
+            if (i < D_NWJ + D_NPJ) issue_piece(ss, fill, i);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -474,7 +486,11 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     cur.q = jblk; cur.chunk = 0;
     if (cur.q >= nitems) return;
     decode(cur);
-    issue_stage(cur, smd);
+    {
+        const StageSrc ss = stage_src(cur, true);
+#pragma unroll
+        for (int j = 0; j < D_NWJ + D_NPJ; ++j) issue_piece(ss, smd, j);
+    }
     nxt = cur;
     auto advance = [&](ItemPos& it) {
         if (++it.chunk == p.nchunks) {
@@ -486,8 +502,8 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     advance(nxt);
     // one step of the pipeline; `cur_buf` holds the landed stage, `fill` takes the next copy
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
-        if (nxt.q < nitems && !(p.dbg & 1)) issue_stage(nxt, fill);
-        if (!(p.dbg & 2)) run_stage(cur_buf);
+        const StageSrc ss = stage_src(nxt, nxt.q < nitems && !(p.dbg & 1));
+        run_stage(cur_buf, fill, ss);
         if (cur.chunk == p.nchunks - 1) {
             if (!(p.dbg & 4)) epilogue(cur);
             zero_acc();
