@@ -351,6 +351,154 @@ __global__ void conv_k1_bwd_weight_kernel(const T* __restrict__ x, const float* 
     reduce_phases_atomic<1>(&bsum, G, rpp, sm, db, [&](int g, int v) -> long long { return g == 0 ? 0 : -1; });
 }
 
+// ------------------------------------------------------------------ 1x1 conv to one channel
+// Streaming versions for R = 1, pad = 0 (the decoder's output layer): a thread owns one 16-byte
+// channel chunk for the whole kernel, a row (pixel) is spread over G = C / chunk lanes, rows are
+// taken in batches of U with all loads issued first.  32-bit row indices.
+__device__ __attribute__((aligned(16))) uint4 g_zero16s;  // never written: stays zero
+
+template <typename T> __device__ __forceinline__ void decode16(const uint4& r, float* f);
+template <> __device__ __forceinline__ void decode16<float>(const uint4& r, float* f) {
+    f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void decode16<bf16>(const uint4& r, float* f) {
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void pw1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ y, unsigned M,
+                                                     unsigned per, int C, int Creal) {
+    constexpr int EPC = ElemTraits<T>::EPC, U = 8;
+    const int G = C / EPC, rpp = NT / G;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    float wv[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) wv[e] = cg * EPC + e < Creal ? w[cg * EPC + e] : 0.f;
+    const float bias = b[0];
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
+    for (unsigned r = r0 + phase; r < r1 + phase; r += rpp * U) {   // uniform trip count per group
+        uint4 raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * rpp;
+            raw[u] = *reinterpret_cast<const uint4*>(rr < r1 ? (const void*)(x + (size_t)rr * C + cg * EPC) : (const void*)&g_zero16s);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float f[EPC];
+            decode16<T>(raw[u], f);
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) a += f[e] * wv[e];
+            for (int off = G >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+            const unsigned rr = r + u * rpp;
+            if (cg == 0 && rr < r1) y[rr] = a + bias;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void pw1_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          const T* __restrict__ aux, T* __restrict__ dx, unsigned M,
+                                                          unsigned per, int C, int Creal) {
+    constexpr int EPC = ElemTraits<T>::EPC, U = 8;
+    const int G = C / EPC, rpp = NT / G;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    float wv[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) wv[e] = cg * EPC + e < Creal ? w[cg * EPC + e] : 0.f;
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
+    for (unsigned r = r0 + phase; r < r1; r += rpp * U) {
+        uint4 raw[U];
+        float g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * rpp;
+            const bool ok = rr < r1;
+            g[u] = dy[ok ? rr : r];
+            if (aux) raw[u] = *reinterpret_cast<const uint4*>(ok ? (const void*)(aux + (size_t)rr * C + cg * EPC) : (const void*)&g_zero16s);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * rpp;
+            if (rr >= r1) break;
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = g[u] * wv[e];
+            if (aux) {
+                float a[EPC];
+                decode16<T>(raw[u], a);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o[e] = a[e] > 0.f ? o[e] : 0.f;
+            }
+            store_chunk<T>(dx + (size_t)rr * C + cg * EPC, o);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void pw1_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dw, float* __restrict__ db, unsigned M,
+                                                            unsigned per, int C, int Creal) {
+    constexpr int EPC = ElemTraits<T>::EPC, U = 8;
+    __shared__ float sm[8 * NT];
+    const int G = C / EPC, rpp = NT / G;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    float acc[EPC + 1];
+#pragma unroll
+    for (int e = 0; e <= EPC; ++e) acc[e] = 0.f;
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
+    for (unsigned r = r0 + phase; r < r1; r += rpp * U) {
+        uint4 raw[U];
+        float g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * rpp;
+            const bool ok = rr < r1;
+            const float gv = dy[ok ? rr : r];
+            g[u] = ok ? gv : 0.f;
+            raw[u] = *reinterpret_cast<const uint4*>(ok ? (const void*)(x + (size_t)rr * C + cg * EPC) : (const void*)&g_zero16s);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float f[EPC];
+            decode16<T>(raw[u], f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += g[u] * f[e];
+            acc[EPC] += g[u];
+        }
+    }
+    reduce_phases_atomic<EPC>(acc, G, rpp, sm, dw, [&](int gq, int v) -> long long {
+        const int c = gq * EPC + v;
+        return c < Creal ? (long long)c : -1;
+    });
+    reduce_phases_atomic<1>(acc + EPC, G, rpp, sm, db, [&](int gq, int v) -> long long { return gq == 0 ? 0 : -1; });
+}
+
+struct RowSplit { unsigned per; int grid; };
+inline RowSplit split_rows_small(long long items, int step, int cap) {
+    long long grid = (items + step - 1) / step;
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    long long per = (items + grid - 1) / grid;
+    per = (per + step - 1) / step * step;
+    grid = (items + per - 1) / per;
+    RowSplit s;
+    s.per = (unsigned)per; s.grid = (int)grid;
+    return s;
+}
+inline bool pw1_ok(int dtype, int C, int R, int pad, long long M) {
+    const int g = C / (dtype == SF_BF16 ? 8 : 4);
+    return R == 1 && pad == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 && M < 0x7fffffffLL;
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL)                                       \
@@ -448,6 +596,13 @@ extern "C" int sf_conv_k1_fwd(const void* x, int dtype, const float* w, const fl
     int lpp = 1;
     while (lpp < C / epc && lpp < 64) lpp <<= 1;
     const long long total = (long long)N * OH * OW;
+    if (pw1_ok(dtype, C, R, pad, total)) {
+        const RowSplit sp = split_rows_small(total, (NT / (C / epc)) * 8, 4096);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_fwd_kernel<T>, dim3(sp.grid), dim3(NT), 0, (hipStream_t)stream,
+                                             (const T*)x, w, b, y, (unsigned)total, sp.per, C, Creal));
+        SF_LAUNCH_CHECK("sf_conv_k1_fwd");
+        return SF_OK;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(conv_k1_fwd_kernel<T>, dim3(grid_for(total * lpp)), dim3(NT), 0,
                                          (hipStream_t)stream, (const T*)x, w, b, y, N, H, W, C, Creal, R, pad, OH, OW,
                                          lpp));
@@ -461,6 +616,14 @@ extern "C" int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* 
     int OH, OW;
     if (int rc = k1_dims("sf_conv_k1_bwd_data", dtype, N, H, W, C, Creal, R, pad, &OH, &OW)) return rc;
     const int epc = dtype == SF_BF16 ? 8 : 4;
+    if (pw1_ok(dtype, C, R, pad, (long long)N * H * W)) {
+        const long long M = (long long)N * H * W;
+        const RowSplit sp = split_rows_small(M, (NT / (C / epc)) * 8, 4096);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_bwd_data_kernel<T>, dim3(sp.grid), dim3(NT), 0, (hipStream_t)stream, dy,
+                                             w, (const T*)aux, (T*)dx, (unsigned)M, sp.per, C, Creal));
+        SF_LAUNCH_CHECK("sf_conv_k1_bwd_data");
+        return SF_OK;
+    }
     const long long total = (long long)N * H * W * (C / epc);
     DISPATCH_T(dtype, hipLaunchKernelGGL(conv_k1_bwd_data_kernel<T>, dim3(grid_for(total)), dim3(NT), 0,
                                          (hipStream_t)stream, dy, w, (const T*)aux, (T*)dx, N, H, W, C, Creal, R, pad,
@@ -483,6 +646,13 @@ extern "C" int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, 
     const int rpp = NT / (C / epc);
     const long long M = (long long)N * OH * OW;
     int grid = (int)((M + rpp * 16 - 1) / (rpp * 16)); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
+    if (pw1_ok(dtype, C, R, pad, M)) {
+        const RowSplit sp = split_rows_small(M, rpp * 8, 1024);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_bwd_weight_kernel<T>, dim3(sp.grid), dim3(NT), 0, s, (const T*)x, dy, dw,
+                                             db, (unsigned)M, sp.per, C, Creal));
+        SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
+        return SF_OK;
+    }
     if (R == 1) {
         DISPATCH_T(dtype, hipLaunchKernelGGL((conv_k1_bwd_weight_kernel<T, 1>), dim3(grid), dim3(NT), 0, s, (const T*)x,
                                              dy, dw, db, N, H, W, C, Creal, R, pad, OH, OW));
