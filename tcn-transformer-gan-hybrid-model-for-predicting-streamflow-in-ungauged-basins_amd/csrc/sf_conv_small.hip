@@ -482,6 +482,164 @@ __global__ __launch_bounds__(NT) void pw1_bwd_weight_kernel(const T* __restrict_
     reduce_phases_atomic<1>(acc + EPC, G, rpp, sm, db, [&](int gq, int v) -> long long { return gq == 0 ? 0 : -1; });
 }
 
+// ------------------------------------------------------------------ RxR conv to one channel
+// (PatchGAN head, R = 4, stride 1).  Weights sit in LDS as [tap][channel]; loads of a work item
+// are issued together with clamped / zero-chunk addresses; 32-bit indices.
+constexpr int HEAD_MAX_W = 16 * 512;  // taps x channels the LDS weight copy holds
+
+__device__ __forceinline__ void head_stage_weights(float* sw, const float* __restrict__ w, int C, int Creal, int RS) {
+    for (int i = threadIdx.x; i < RS * C; i += blockDim.x) {
+        const int t = i / C, c = i - t * C;
+        sw[i] = c < Creal ? w[c * RS + t] : 0.f;
+    }
+    __syncthreads();
+}
+
+// a group of G lanes per output pixel
+template <typename T>
+__global__ __launch_bounds__(NT) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ y, unsigned total,
+                                                      int H, int W, int C, int Creal, int R, int pad, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    __shared__ float sw[HEAD_MAX_W];
+    const int RS = R * R;
+    head_stage_weights(sw, w, C, Creal, RS);
+    const int G = C / EPC, ppb = NT / G;
+    const int cg = threadIdx.x % G, slot = threadIdx.x / G;
+    const float bias = b[0];
+    for (unsigned o0 = blockIdx.x * ppb; o0 < total; o0 += gridDim.x * ppb) {
+        const unsigned o = o0 + slot;
+        const bool live = o < total;
+        const unsigned oc = live ? o : o0;
+        const unsigned q = oc / (unsigned)OW, ow = oc - q * OW;
+        const unsigned n = q / (unsigned)OH, oh = q - n * OH;
+        float acc = 0.f;
+        for (int t0 = 0; t0 < RS; t0 += 8) {
+            uint4 raw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = t0 + k;
+                const int ty = t / R, tx = t - ty * R;
+                const int iy = (int)oh - pad + ty, ix = (int)ow - pad + tx;
+                const bool ok = live && t < RS && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                raw[k] = *reinterpret_cast<const uint4*>(ok ? (const void*)(x + (((size_t)n * H + iy) * W + ix) * C + cg * EPC)
+                                                            : (const void*)&g_zero16s);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = t0 + k < RS ? t0 + k : 0;
+                float f[EPC];
+                decode16<T>(raw[k], f);
+                const float* wt = sw + t * C + cg * EPC;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc += f[e] * wt[e];
+            }
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (live && cg == 0) y[o] = acc + bias;
+    }
+}
+
+// one thread per (input pixel, channel chunk)
+template <typename T>
+__global__ __launch_bounds__(NT) void head_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                           const T* __restrict__ aux, T* __restrict__ dx, unsigned total,
+                                                           int H, int W, int C, int Creal, int R, int pad, int OH,
+                                                           int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    __shared__ float sw[HEAD_MAX_W];
+    const int RS = R * R;
+    head_stage_weights(sw, w, C, Creal, RS);
+    const int G = C / EPC, ppb = NT / G;
+    const int cg = threadIdx.x % G, slot = threadIdx.x / G;
+    for (unsigned o0 = blockIdx.x * ppb; o0 < total; o0 += gridDim.x * ppb) {
+        const unsigned o = o0 + slot;
+        if (o >= total) continue;
+        const unsigned q = o / (unsigned)W, ix = o - q * W;
+        const unsigned n = q / (unsigned)H, iy = q - n * H;
+        float g[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int ty = t / R, tx = t - ty * R;
+            const int oh = (int)iy + pad - ty, ow = (int)ix + pad - tx;
+            const bool ok = t < RS && oh >= 0 && oh < OH && ow >= 0 && ow < OW;
+            const float v = dy[ok ? ((size_t)n * OH + oh) * OW + ow : 0];
+            g[t] = ok ? v : 0.f;
+        }
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float* wt = sw + (t < RS ? t : 0) * C + cg * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += g[t] * wt[e];
+        }
+        if (aux) {
+            float a[EPC];
+            load_chunk<T>(aux + (size_t)o * C + cg * EPC, a);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = a[e] > 0.f ? acc[e] : 0.f;
+        }
+        store_chunk<T>(dx + (size_t)o * C + cg * EPC, acc);
+    }
+}
+
+// thread = (tap, channel chunk); the workgroup walks its range of output pixels together
+template <typename T>
+__global__ void head_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                       float* __restrict__ db, unsigned M, unsigned per, int H, int W, int C, int Creal,
+                                       int R, int pad, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC, U = 8;
+    const int G = C / EPC, RS = R * R;
+    const int cg = threadIdx.x % G, t = threadIdx.x / G;
+    const int ty = t / R, tx = t - ty * R;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    float bsum = 0.f;
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
+    for (unsigned m0 = r0; m0 < r1; m0 += U) {
+        uint4 raw[U];
+        float g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned m = m0 + u;
+            const bool live = m < r1;
+            const unsigned mc = live ? m : m0;
+            const unsigned q = mc / (unsigned)OW, ow = mc - q * OW;
+            const unsigned n = q / (unsigned)OH, oh = q - n * OH;
+            const int iy = (int)oh - pad + ty, ix = (int)ow - pad + tx;
+            const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float gv = dy[mc];
+            g[u] = live ? gv : 0.f;
+            raw[u] = *reinterpret_cast<const uint4*>(ok ? (const void*)(x + (((size_t)n * H + iy) * W + ix) * C + cg * EPC)
+                                                        : (const void*)&g_zero16s);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float f[EPC];
+            decode16<T>(raw[u], f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += g[u] * f[e];
+            bsum += g[u];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = cg * EPC + e;
+        if (c < Creal) unsafeAtomicAdd(dw + (size_t)c * RS + t, acc[e]);
+    }
+    if (threadIdx.x == 0) unsafeAtomicAdd(db, bsum);
+}
+
+inline bool head_ok(int dtype, int C, int R, long long items) {
+    const int g = C / (dtype == SF_BF16 ? 8 : 4);
+    return R >= 1 && R <= 4 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 && R * R * C <= HEAD_MAX_W && g * R * R <= 1024 &&
+           (g * R * R) % 64 == 0 && items < 0x7fffffffLL;
+}
+
 struct RowSplit { unsigned per; int grid; };
 inline RowSplit split_rows_small(long long items, int step, int cap) {
     long long grid = (items + step - 1) / step;
@@ -603,6 +761,14 @@ extern "C" int sf_conv_k1_fwd(const void* x, int dtype, const float* w, const fl
         SF_LAUNCH_CHECK("sf_conv_k1_fwd");
         return SF_OK;
     }
+    if (head_ok(dtype, C, R, total)) {
+        const int ppb = NT / (C / epc);
+        long long grid = (total + ppb - 1) / ppb; if (grid > 8192) grid = 8192;
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)stream,
+                                             (const T*)x, w, b, y, (unsigned)total, H, W, C, Creal, R, pad, OH, OW));
+        SF_LAUNCH_CHECK("sf_conv_k1_fwd");
+        return SF_OK;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(conv_k1_fwd_kernel<T>, dim3(grid_for(total * lpp)), dim3(NT), 0,
                                          (hipStream_t)stream, (const T*)x, w, b, y, N, H, W, C, Creal, R, pad, OH, OW,
                                          lpp));
@@ -621,6 +787,16 @@ extern "C" int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* 
         const RowSplit sp = split_rows_small(M, (NT / (C / epc)) * 8, 4096);
         DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_bwd_data_kernel<T>, dim3(sp.grid), dim3(NT), 0, (hipStream_t)stream, dy,
                                              w, (const T*)aux, (T*)dx, (unsigned)M, sp.per, C, Creal));
+        SF_LAUNCH_CHECK("sf_conv_k1_bwd_data");
+        return SF_OK;
+    }
+    if (head_ok(dtype, C, R, (long long)N * H * W)) {
+        const long long items = (long long)N * H * W;
+        const int ppb = NT / (C / epc);
+        long long grid = (items + ppb - 1) / ppb; if (grid > 8192) grid = 8192;
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_bwd_data_kernel<T>, dim3((unsigned)grid), dim3(NT), 0,
+                                             (hipStream_t)stream, dy, w, (const T*)aux, (T*)dx, (unsigned)items, H, W, C,
+                                             Creal, R, pad, OH, OW));
         SF_LAUNCH_CHECK("sf_conv_k1_bwd_data");
         return SF_OK;
     }
@@ -650,6 +826,13 @@ extern "C" int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, 
         const RowSplit sp = split_rows_small(M, rpp * 8, 1024);
         DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_bwd_weight_kernel<T>, dim3(sp.grid), dim3(NT), 0, s, (const T*)x, dy, dw,
                                              db, (unsigned)M, sp.per, C, Creal));
+        SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
+        return SF_OK;
+    }
+    if (head_ok(dtype, C, R, M)) {
+        const RowSplit sp = split_rows_small(M, 8, 512);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_bwd_weight_kernel<T>, dim3(sp.grid), dim3((C / epc) * R * R), 0, s,
+                                             (const T*)x, dy, dw, db, (unsigned)M, sp.per, H, W, C, Creal, R, pad, OH, OW));
         SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
         return SF_OK;
     }
