@@ -204,6 +204,38 @@ def test_discriminator_f32(sf, size):
             close(p.grad, g[f"g{size}_{n}"], 1e-3)
 
 
+@pytest.mark.parametrize("size", [64])
+def test_discriminator_bf16(sf, size):
+    """bf16 PatchGAN (first-layer, stride-2 GEMM, BatchNorm + LeakyReLU, head kernels) against
+    the f32 reference vectors.  Stated tolerances: output 5e-2 of its max; gradients 0.15 (input) and 0.25 (parameters)
+    in relative L2 norm -- LeakyReLU sign flips of bf16-rounded
+    pre-activations behind BatchNorm statistics over as few as 98 samples move single elements
+    by much more, so an element-wise bound would not be meaningful here."""
+    g = golden("discriminator")
+    d = sf.PatchDiscriminator(1, 16).to(DEV)
+    load_gold(d, "disc")
+    d.train()
+    x = G.gold_tensor(f"disc/x{size}", (2, 1, size, size)).to(DEV).requires_grad_(True)
+    sf.set_compute_dtype(torch.bfloat16)
+    try:
+        y = d(x)
+        (y * G.gold_tensor(f"disc/gy{size}", tuple(y.shape)).to(DEV)).sum().backward()
+    finally:
+        sf.set_compute_dtype(None)
+    close(y, g[f"y{size}"], 5e-2)
+
+    def rel_l2(a, b):
+        a, b = a.detach().cpu().double().numpy(), np.asarray(b, dtype=np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+    assert rel_l2(x.grad, g[f"gx{size}"]) <= 0.15
+    for n, p in d.named_parameters():
+        if n in ("model.2.0.bias", "model.3.0.bias", "model.4.0.bias"):
+            continue
+        e = rel_l2(p.grad, g[f"g{size}_{n}"])
+        assert e <= 0.25, (n, e)
+
+
 # ------------------------------------------------------------------ losses
 def station_cases(H, W):
     pos = [
