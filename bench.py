@@ -107,7 +107,7 @@ def main():
 
     for i in range(a.warmup):
         ld = step(i)
-    tags = ("dec_conv1_fprop", "dec_conv1_dgrad", "dec_conv1_wgrad")
+    tags = ("conv3_dma_kernel", "dec_conv1_wgrad")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -130,13 +130,11 @@ def main():
     bad = trainer.saw_nan_or_inf()
 
     if rank == 0:
-        # dominant kernel: the decoder's first conv (256 -> 64 channels at 400x400), forward,
-        # data gradient and weight gradient, 47.19 GFLOP per sample each
-        flops = 2.0 * a.batch * 400 * 400 * 64 * 2304
-        per = {t: ops.timed_ms(t) for t in tags}
-        n_l = sum(v[0] for v in per.values())
-        ms = sum(v[0] * v[1] for v in per.values()) / max(n_l, 1)
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # dominant kernel: conv3_dma_kernel, the 3x3 forward / data-gradient conv (six launches per
+        # step: decoder conv1 and conv2, encoder conv2, forward and data gradient each).
+        # Algorithmic flops of a launch = 2 * N*H*W * C * K * 9, recorded with its HIP-event time.
+        n_l, ms_l, achieved = ops.timed_tflops("conv3_dma_kernel")
+        n_w, ms_w = ops.timed_ms("dec_conv1_wgrad")
         out = {
             "metric": "train samples/sec (node) @10ch 200x200 T=5",
             "value": round(world * a.batch * a.steps / dt, 3), "unit": "samples/s",
@@ -147,8 +145,8 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_kernel (decoder conv1 fprop/dgrad/wgrad)",
-                         "ms_per_launch": {t: round(v[1], 4) for t, v in per.items()}},
+                         "kernel": "conv3_dma_kernel", "launches": n_l, "ms_per_launch": round(ms_l, 4),
+                         "other": {"wgrad3_dma_kernel (decoder conv1, 1.51 TFLOP/launch) ms": round(ms_w, 4)}},
             "final_loss": round(loss, 6), "nan_or_inf": bad,
         }
         if world == 1 and not a.no_cpu_baseline:

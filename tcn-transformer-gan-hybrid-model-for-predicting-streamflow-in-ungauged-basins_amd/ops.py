@@ -132,7 +132,18 @@ def timed_ms(tag: str):
     if not ev:
         return 0, 0.0
     torch.cuda.synchronize()
-    return len(ev), sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    return len(ev), sum(r[0].elapsed_time(r[1]) for r in ev) / len(ev)
+
+
+def timed_tflops(tag: str):
+    """(number of launches, mean ms per launch, TFLOP/s = recorded flops / recorded time)."""
+    ev = TIMED.get(tag, [])
+    if not ev:
+        return 0, 0.0, 0.0
+    torch.cuda.synchronize()
+    ms = sum(r[0].elapsed_time(r[1]) for r in ev)
+    fl = sum(r[2] for r in ev if len(r) > 2)
+    return len(ev), ms / len(ev), (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
 
 
 def gemm(desc: GemmDesc, A, B, out, bias=None, aux=None, tag: Optional[str] = None):
@@ -187,6 +198,8 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
     if x.dtype == torch.bfloat16 and C % 16 == 0 and not FORCE_GENERIC_CONV:
         _dev(x, wp, out, bias, aux)
         rec = TIMED.get(tag) if tag is not None else None
+        if rec is None and C % 32 == 0:
+            rec = TIMED.get("conv3_dma_kernel")   # every launch of the persistent kernel
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -196,7 +209,7 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
                                 aux_mode, code_of(out.dtype), _stream()), "sf_conv3x3")
         if rec is not None:
             e1.record()
-            rec.append((e0, e1))
+            rec.append((e0, e1, 2.0 * N * H * W * C * K * 9))
         return
     geom = conv_geom(N, H, W, C, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)))
     conv_fprop(x, wp, out, geom, K, bias=bias, act=act, aux=aux, aux_mode=aux_mode, tag=tag)
