@@ -585,53 +585,65 @@ __global__ __launch_bounds__(NT) void head_bwd_data_kernel(const float* __restri
     }
 }
 
-// thread = (tap, channel chunk); the workgroup walks its range of output pixels together
+// dw[c][t] = sum over INPUT pixels of x[pixel][c] * dy[pixel + pad - tap t]: a thread owns one
+// channel chunk, loads each input chunk once and applies all RS taps to it (the dy values are
+// scalars from a tiny tensor), so x crosses the memory system once.
 template <typename T>
-__global__ void head_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                       float* __restrict__ db, unsigned M, unsigned per, int H, int W, int C, int Creal,
-                                       int R, int pad, int OH, int OW) {
-    constexpr int EPC = ElemTraits<T>::EPC, U = 8;
-    const int G = C / EPC, RS = R * R;
-    const int cg = threadIdx.x % G, t = threadIdx.x / G;
-    const int ty = t / R, tx = t - ty * R;
-    float acc[EPC];
+__global__ __launch_bounds__(NT) void head_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ dw, float* __restrict__ db,
+                                                             unsigned M, unsigned per, unsigned Mout, int H, int W,
+                                                             int C, int Creal, int R, int pad, int OH, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC, U = 2;
+    constexpr int NV = 16 * EPC;
+    __shared__ float sm[8 * NT];
+    const int G = C / EPC, rpp = NT / G, RS = R * R;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    float acc[NV];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-    float bsum = 0.f;
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
     const unsigned r0 = blockIdx.x * per;
     const unsigned r1 = r0 + per < M ? r0 + per : M;
-    for (unsigned m0 = r0; m0 < r1; m0 += U) {
+    for (unsigned r = r0 + phase; r < r1; r += rpp * U) {
         uint4 raw[U];
-        float g[U];
+        float g[U][16];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const unsigned m = m0 + u;
-            const bool live = m < r1;
-            const unsigned mc = live ? m : m0;
-            const unsigned q = mc / (unsigned)OW, ow = mc - q * OW;
-            const unsigned n = q / (unsigned)OH, oh = q - n * OH;
-            const int iy = (int)oh - pad + ty, ix = (int)ow - pad + tx;
-            const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const float gv = dy[mc];
-            g[u] = live ? gv : 0.f;
-            raw[u] = *reinterpret_cast<const uint4*>(ok ? (const void*)(x + (((size_t)n * H + iy) * W + ix) * C + cg * EPC)
-                                                        : (const void*)&g_zero16s);
+            const unsigned rr = r + u * rpp;
+            const bool live = rr < r1;
+            const unsigned mc = live ? rr : r;
+            const unsigned q = mc / (unsigned)W, ix = mc - q * W;
+            const unsigned n = q / (unsigned)H, iy = q - n * H;
+            raw[u] = *reinterpret_cast<const uint4*>(live ? (const void*)(x + (size_t)mc * C + cg * EPC) : (const void*)&g_zero16s);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int ty = t / R, tx = t - ty * R;
+                const int oh = (int)iy + pad - ty, ow = (int)ix + pad - tx;
+                const bool ok = live && t < RS && oh >= 0 && oh < OH && ow >= 0 && ow < OW;
+                const float v = dy[ok ? ((size_t)n * OH + oh) * OW + ow : 0];
+                g[u][t] = ok ? v : 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float f[EPC];
             decode16<T>(raw[u], f);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[e] += g[u] * f[e];
-            bsum += g[u];
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[t * EPC + e] += g[u][t] * f[e];
         }
     }
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        const int c = cg * EPC + e;
-        if (c < Creal) unsafeAtomicAdd(dw + (size_t)c * RS + t, acc[e]);
+    reduce_phases_atomic<NV>(acc, G, rpp, sm, dw, [&](int gq, int v) -> long long {
+        const int t = v / EPC, c = gq * EPC + v % EPC;
+        return (t < RS && c < Creal) ? (long long)c * RS + t : -1;
+    });
+    // db = sum(dy): the first workgroup adds it
+    if (blockIdx.x == 0) {
+        float bs = 0.f;
+        for (unsigned i = threadIdx.x; i < Mout; i += NT) bs += dy[i];
+        bs = block_sum_256(bs, sm);
+        if (threadIdx.x == 0) unsafeAtomicAdd(db, bs);
     }
-    if (threadIdx.x == 0) unsafeAtomicAdd(db, bsum);
 }
 
 inline bool head_ok(int dtype, int C, int R, long long items) {
@@ -829,10 +841,11 @@ extern "C" int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, 
         SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
         return SF_OK;
     }
-    if (head_ok(dtype, C, R, M)) {
-        const RowSplit sp = split_rows_small(M, 8, 512);
-        DISPATCH_T(dtype, hipLaunchKernelGGL(head_bwd_weight_kernel<T>, dim3(sp.grid), dim3((C / epc) * R * R), 0, s,
-                                             (const T*)x, dy, dw, db, (unsigned)M, sp.per, H, W, C, Creal, R, pad, OH, OW));
+    if (head_ok(dtype, C, R, (long long)N * H * W)) {
+        const long long Min = (long long)N * H * W;
+        const RowSplit sp = split_rows_small(Min, (NT / (C / epc)) * 2, 256);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_bwd_weight_kernel<T>, dim3(sp.grid), dim3(NT), 0, s, (const T*)x, dy, dw,
+                                             db, (unsigned)Min, sp.per, (unsigned)M, H, W, C, Creal, R, pad, OH, OW));
         SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
         return SF_OK;
     }

@@ -105,25 +105,28 @@ __global__ __launch_bounds__(NTW, 2) void wgrad_patch_kernel(WPParams p) {
         const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
         const long long based = ((long long)n * p.OH + oy0) * p.OW + ox0;
         const long long basex = ((long long)n * p.IH + iy0) * p.IW + ix0;
+        // buffer loads: 32-bit byte offsets into the tile's image, out-of-range offsets return
+        // zeros (padding, partial tiles) -- no branch around a load
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.dout + (size_t)n * p.OH * p.OW * p.Kd), 0, (unsigned)(p.OH * p.OW * p.Kd * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.x + (size_t)n * p.IH * p.IW * p.Cx), 0, (unsigned)(p.IH * p.IW * p.Cx * 2), 0x00020000);
+        const int doff = ((oy0 * p.OW + ox0) * p.Kd + kt * 64 + cc * 8) * 2;
+        const int xoff = ((iy0 * p.IW + ix0) * p.Cx + ct * 64 + cc * 8) * 2;
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (d_lyx[i] >= 0 && d_col_ok) {
-                const int ly = d_lyx[i] >> 16, lx = d_lyx[i] & 0xffff;
-                if (oy0 + ly < p.OH && ox0 + lx < p.OW)
-                    v = *reinterpret_cast<const uint4*>(p.dout + (based + d_rel[i]) * p.Kd + kt * 64 + cc * 8);
-            }
-            rd[i] = v;
+            const int ly = d_lyx[i] >> 16, lx = d_lyx[i] & 0xffff;
+            const bool ok = d_lyx[i] >= 0 && d_col_ok && oy0 + ly < p.OH && ox0 + lx < p.OW;
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(drs, ok ? doff + d_rel[i] * p.Kd * 2 : (int)0x80000000, 0, 0);
+            rd[i] = make_uint4(v[0], v[1], v[2], v[3]);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (x_pyx[i] >= 0 && x_col_ok) {
-                const int gy = iy0 + (x_pyx[i] >> 16), gx = ix0 + (x_pyx[i] & 0xffff);
-                if (gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW)
-                    v = *reinterpret_cast<const uint4*>(p.x + (basex + x_rel[i]) * p.Cx + ct * 64 + cc * 8);
-            }
-            rx[i] = v;
+            const int gy = iy0 + (x_pyx[i] >> 16), gx = ix0 + (x_pyx[i] & 0xffff);
+            const bool ok = x_pyx[i] >= 0 && x_col_ok && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW;
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xoff + x_rel[i] * p.Cx * 2 : (int)0x80000000, 0, 0);
+            rx[i] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
     auto store_tile = [&]() {
