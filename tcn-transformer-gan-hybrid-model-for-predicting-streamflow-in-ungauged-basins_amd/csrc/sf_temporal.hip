@@ -29,6 +29,30 @@ __device__ __forceinline__ float drop_mask(float p, unsigned long long seed, int
     return rand_u(seed, idx) >= p ? 1.0f / (1.0f - p) : 0.f;
 }
 
+// acc[t] = wrow . v[t] for the T tokens (v in LDS, row stride ldv): the weight row is read once,
+// four 16-byte loads in flight
+__device__ __forceinline__ void dot_row_tokens(const float* __restrict__ wrow, const float* __restrict__ v, int ldv,
+                                               int n, int T, float* acc) {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
+    for (int d = 0; d < n; d += 16) {
+        float4 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = *reinterpret_cast<const float4*>(wrow + (d + 4 * k < n ? d + 4 * k : 0));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (d + 4 * k < n) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+                    if (t < T) {
+                        const float* vv = v + t * ldv + d + 4 * k;
+                        acc[t] += w[k].x * vv[0] + w[k].y * vv[1] + w[k].z * vv[2] + w[k].w * vv[3];
+                    }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ float dot_row(const float* __restrict__ wrow, const float* __restrict__ v, int n) {
     float a = 0.f;
     for (int d = 0; d < n; d += 4) {
@@ -111,8 +135,10 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
     // packed q,k,v projection
     for (int o = tid; o < 3 * D; o += NT) {
         const float bb = bin[o];
+        float dacc[MAXT];
+        dot_row_tokens(Win + (size_t)o * D, xs, D, D, T, dacc);
         for (int t = 0; t < T; ++t) {
-            const float v = dot_row(Win + (size_t)o * D, xs + t * D, D) + bb;
+            const float v = dacc[t] + bb;
             qkv[t * 3 * D + o] = v;
             if (sv) s_qkv[t * 3 * D + o] = v;
         }
@@ -150,8 +176,10 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
     __syncthreads();
     for (int o = tid; o < D; o += NT) {
         const float bb = bo[o];
+        float dacc[MAXT];
+        dot_row_tokens(Wo + (size_t)o * D, ctx, D, D, T, dacc);
         for (int t = 0; t < T; ++t) {
-            const float v = dot_row(Wo + (size_t)o * D, ctx + t * D, D) + bb;
+            const float v = dacc[t] + bb;
             tmp[t * D + o] = xs[t * D + o] + v * drop_mask(p, seed, b, 1, t * D + o);
         }
     }
@@ -161,8 +189,10 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
     if (sv) for (int i = tid; i < T * D; i += NT) s_x1[i] = x1[i];
     for (int f = tid; f < F; f += NT) {
         const float bb = b1[f];
+        float dacc[MAXT];
+        dot_row_tokens(W1 + (size_t)f * D, x1, D, D, T, dacc);
         for (int t = 0; t < T; ++t) {
-            float v = dot_row(W1 + (size_t)f * D, x1 + t * D, D) + bb;
+            float v = dacc[t] + bb;
             v = v > 0.f ? v * drop_mask(p, seed, b, 2, t * F + f) : 0.f;
             hd[t * F + f] = v;
             if (sv) s_hd[t * F + f] = v;
@@ -171,8 +201,10 @@ __global__ __launch_bounds__(NT) void transformer_fwd_kernel(const float* __rest
     __syncthreads();
     for (int o = tid; o < D; o += NT) {
         const float bb = b2[o];
+        float dacc[MAXT];
+        dot_row_tokens(W2 + (size_t)o * F, hd, F, F, T, dacc);
         for (int t = 0; t < T; ++t) {
-            const float v = dot_row(W2 + (size_t)o * F, hd + t * F, F) + bb;
+            const float v = dacc[t] + bb;
             tmp[t * D + o] = x1[t * D + o] + v * drop_mask(p, seed, b, 3, t * D + o);
         }
     }
@@ -203,6 +235,81 @@ __device__ __forceinline__ void layer_norm_bwd_tokens(const float* g, const floa
     }
 }
 
+// out[t][j] (+)= sum_o in[t][o] * Wm[o][j] for the T tokens of the sample (in / out in LDS,
+// Wm row-major in global memory, NJ % 4 == 0).  A thread owns four consecutive j; when there are
+// fewer such groups than threads the reduction range is split over NT / (NJ/4) parts that are
+// summed through `scratch` (parts * MAXT * NJ floats).  The weight loads of eight reduction
+// steps are issued together.  Ends with a barrier.
+__device__ __forceinline__ void tok_matmul(const float* __restrict__ in, int ldin, const float* __restrict__ Wm,
+                                           int ldw, int NO, int NJ, int T, float* __restrict__ out, int ldout,
+                                           bool add, float* __restrict__ scratch) {
+    const int tid = threadIdx.x;
+    const int J4 = NJ >> 2;
+    const int parts = J4 >= NT ? 1 : NT / J4;
+    const int per = (NO + parts - 1) / parts;
+    for (int g0 = 0; g0 < J4; g0 += NT) {
+        const int j4 = parts == 1 ? g0 + tid : tid % J4;
+        const int part = parts == 1 ? 0 : tid / J4;
+        const bool live = j4 < J4 && part < parts;
+        float acc[MAXT][4];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+        if (live) {
+            const int o0 = part * per, o1 = o0 + per < NO ? o0 + per : NO;
+            const float* wp = Wm + 4 * j4;
+            for (int ob = o0; ob < o1; ob += 8) {
+                float4 w[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int o = ob + k < o1 ? ob + k : o0;
+                    w[k] = *reinterpret_cast<const float4*>(wp + (size_t)o * ldw);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (ob + k < o1) {
+#pragma unroll
+                        for (int t = 0; t < MAXT; ++t)
+                            if (t < T) {
+                                const float g = in[t * ldin + ob + k];
+                                acc[t][0] += g * w[k].x; acc[t][1] += g * w[k].y;
+                                acc[t][2] += g * w[k].z; acc[t][3] += g * w[k].w;
+                            }
+                    }
+                }
+            }
+        }
+        if (parts == 1) {
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+                    if (t < T) {
+                        float* o4 = out + t * ldout + 4 * j4;
+                        if (add) { o4[0] += acc[t][0]; o4[1] += acc[t][1]; o4[2] += acc[t][2]; o4[3] += acc[t][3]; }
+                        else { o4[0] = acc[t][0]; o4[1] = acc[t][1]; o4[2] = acc[t][2]; o4[3] = acc[t][3]; }
+                    }
+            }
+        } else {
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+                    if (t < T) {
+                        float* s4 = scratch + ((size_t)part * MAXT + t) * NJ + 4 * j4;
+                        s4[0] = acc[t][0]; s4[1] = acc[t][1]; s4[2] = acc[t][2]; s4[3] = acc[t][3];
+                    }
+            }
+            __syncthreads();
+            for (int i = tid; i < T * NJ; i += NT) {
+                const int t = i / NJ, j = i - t * NJ;
+                float a = 0.f;
+                for (int q = 0; q < parts; ++q) a += scratch[((size_t)q * MAXT + t) * NJ + j];
+                out[t * ldout + j] = add ? out[t * ldout + j] + a : a;
+            }
+            break;  // NJ/4 < NT: a single pass covered every group
+        }
+    }
+    __syncthreads();
+}
+
 // Backward of one encoder layer for one sample.  Gradients of the four weight MATRICES are not
 // formed here: the per-token gradient vectors are written to `gtok` (arrays g_qkv [B,T,3D],
 // g_sa [B,T,D], g_z [B,T,F], g_ff [B,T,D]) and the caller contracts them with the saved
@@ -219,6 +326,7 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
     float* gF = g1 + T * D;         // [T][F]  (also d_ctx)
     float* gq = gF + T * F;         // [T][3D]
     float* gp = gq + T * 3 * D;     // [nh][T][T]
+    float* scr = gp + 8 * T * T;    // tok_matmul scratch
     const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
     const TrSave L(T, D, F);
     const float* s_qkv = save + (size_t)B * L.qkv + (size_t)b * T * 3 * D;
@@ -259,21 +367,14 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
         unsafeAtomicAdd(G.p[7] + o, a);
     }
     // d_hidden -> pre-activation gradient (ReLU and dropout share the saved value's sign)
+    tok_matmul(g0, D, W2, F, D, F, T, gF, F, false, scr);
     for (int f = tid; f < F; f += NT) {
-        float acc[MAXT];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
-        for (int o = 0; o < D; ++o) {
-            const float w = W2[(size_t)o * F + f];
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += g0[t * D + o] * w;
-        }
         float bsum = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
             if (t < T) {
                 const float keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-                const float v = s_hd[t * F + f] > 0.f ? acc[t] * keep : 0.f;
+                const float v = s_hd[t * F + f] > 0.f ? gF[t * F + f] * keep : 0.f;
                 gF[t * F + f] = v;
                 t_z[t * F + f] = v;
                 bsum += v;
@@ -281,19 +382,7 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
         unsafeAtomicAdd(G.p[5] + f, bsum);  // linear1 bias
     }
     __syncthreads();
-    for (int d = tid; d < D; d += NT) {  // d_x1 += dz . W1
-        float acc[MAXT];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
-        for (int f = 0; f < F; ++f) {
-            const float w = W1[(size_t)f * D + d];
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += gF[t * F + f] * w;
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) if (t < T) g1[t * D + d] += acc[t];
-    }
-    __syncthreads();
+    tok_matmul(gF, F, W1, D, F, D, T, g1, D, true, scr);  // d_x1 += dz . W1
     // ---- LayerNorm 1 (g1 = gradient wrt x1)
     for (int d = tid; d < D; d += NT) {
         float a = 0.f, c = 0.f;
@@ -315,19 +404,8 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
         for (int t = 0; t < T; ++t) a += g1[t * D + o];
         unsafeAtomicAdd(G.p[3] + o, a);
     }
-    for (int j = tid; j < D; j += NT) {  // d_ctx -> gF[0 : T*D]
-        float acc[MAXT];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
-        for (int o = 0; o < D; ++o) {
-            const float w = Wo[(size_t)o * D + j];
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += g1[t * D + o] * w;
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) if (t < T) gF[t * D + j] = acc[t];
-    }
     __syncthreads();
+    tok_matmul(g1, D, Wo, D, D, D, T, gF, D, false, scr);  // d_ctx -> gF[0 : T*D]
     // ---- attention: d_pused = d_ctx . v
     const float* qkv = s_qkv;
     for (int i = tid; i < nh * T * T; i += NT) {
@@ -370,18 +448,9 @@ __global__ __launch_bounds__(NT) void transformer_bwd_kernel(const float* __rest
         for (int t = 0; t < T; ++t) a += gq[t * 3 * D + o];
         unsafeAtomicAdd(G.p[1] + o, a);
     }
-    for (int d = tid; d < D; d += NT) {  // dx = g0 + gq . Win
-        float acc[MAXT];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
-        for (int o = 0; o < 3 * D; ++o) {
-            const float w = Win[(size_t)o * D + d];
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) if (t < T) acc[t] += gq[t * 3 * D + o] * w;
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) if (t < T) dx[(size_t)b * T * D + t * D + d] = g0[t * D + d] + acc[t];
-    }
+    __syncthreads();
+    tok_matmul(gq, 3 * D, Win, D, 3 * D, D, T, g0, D, true, scr);  // dx = g0 + gq . Win
+    for (int i = tid; i < T * D; i += NT) dx[(size_t)b * T * D + i] = g0[i];
 }
 
 __global__ void add_pe_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ y,
@@ -570,8 +639,18 @@ extern "C" int sf_transformer_layer_bwd(const float* x, const float* dy, float* 
         SF_REQUIRE(w[i] && dw[i], "sf_transformer_layer_bwd: null weight/grad %d", i);
         W.p[i] = w[i]; G.p[i] = dw[i];
     }
-    const size_t lds = sizeof(float) * ((size_t)T * (2 * D + F + 3 * D) + 8 * T * T);
-    SF_REQUIRE(lds <= 64 * 1024, "sf_transformer_layer_bwd: sequence does not fit in LDS");
+    const int j4 = D / 4, parts = j4 >= NT ? 1 : NT / j4;
+    const size_t lds = sizeof(float) * ((size_t)T * (2 * D + F + 3 * D) + 8 * T * T + (size_t)parts * MAXT * D);
+    SF_REQUIRE(lds <= 160 * 1024 && D % 4 == 0 && F % 4 == 0, "sf_transformer_layer_bwd: sequence does not fit in LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&transformer_bwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            sf_set_error("sf_transformer_layer_bwd: cannot raise the dynamic LDS limit");
+            return SF_ELAUNCH;
+        }
+        attr_set = true;
+    }
     hipLaunchKernelGGL(transformer_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, x, dy, dx, W, G, save, gtok,
                        T, D, F, nhead, p_drop, seed);
     SF_LAUNCH_CHECK("sf_transformer_layer_bwd");
