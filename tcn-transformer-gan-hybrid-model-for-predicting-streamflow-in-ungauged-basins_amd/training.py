@@ -63,6 +63,21 @@ class FlatAdam:
         raise KeyError("parameter not managed by this optimiser")
 
 
+def reduce_ranges(flat_grad: torch.Tensor, skip: Sequence = ()) -> List:
+    """Sum-all-reduce (async) every element of a flat gradient buffer that lies outside the
+    `skip` ranges [(offset, numel), ...] -- those were already reduced from a hook -- in as few
+    calls as the gaps allow.  Skipped ranges are rounded up to the buffer's alignment, like the
+    parameter slots themselves.  Returns the work handles.  Device-agnostic (RCCL or gloo)."""
+    total = flat_grad.numel()
+    works = []
+    pos = 0
+    for (o, n) in sorted(skip) + [(total, 0)]:
+        if o > pos:
+            works.append(dist.all_reduce(flat_grad[pos:o], async_op=True))
+        pos = max(pos, o + (n + _ALIGN - 1) // _ALIGN * _ALIGN)
+    return works
+
+
 class Trainer:
     def __init__(self, config: Dict, device: str = "cuda", distributed: Optional[bool] = None):
         self.config = config
@@ -111,14 +126,7 @@ class Trainer:
             p.register_post_accumulate_grad_hook(hook)
 
     def _reduce_rest(self, opt: FlatAdam, skip: Sequence = ()):
-        """Sum-all-reduce every gradient range not already reduced by a hook, in a few large calls."""
-        total = opt.grad.numel()
-        cuts = sorted(skip)
-        pos = 0
-        for (o, n) in cuts + [(total, 0)]:
-            if o > pos:
-                self._pending.append(dist.all_reduce(opt.grad[pos:o], async_op=True))
-            pos = max(pos, o + (n + _ALIGN - 1) // _ALIGN * _ALIGN)
+        self._pending += reduce_ranges(opt.grad, skip)
 
     def _wait_reduces(self):
         for w in self._pending:
