@@ -319,25 +319,65 @@ template <typename T, int MODE> struct BwdBatch {
                 hh[u] = t - nn[u] * a.H;
                 rx[u] = ld16(ok ? (const void*)(xb + (size_t)rr * a.C) : zsrc());
             }
+            if (a.H >= a.OH && a.W >= a.OW) {
+                // bins overlap by at most one element: a pixel lies in one or two bins per axis.
+                // Always fetch the 2 x 2 candidates (a missing second bin repeats the first with
+                // weight zero) so that the loads are unconditional and issued together.
+                uint4 rg[U][4];
+                float wg[U][4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                Chunk<T>::decode(rx[u], xf[u][0]);
-                float acc[EPC];
+                for (int u = 0; u < U; ++u) {
+                    const int hbin = tabs->hb[hh[u]], wbin = tabs->wb[ww[u]];
+                    const int i0 = hbin & 0xffff, i1 = hbin >> 16, j0 = wbin & 0xffff, j1 = wbin >> 16;
+                    const float wh0 = tabs->ih[i0], wh1 = i1 > i0 ? tabs->ih[i1] : 0.f;
+                    const float ww0 = tabs->iw[j0], ww1 = j1 > j0 ? tabs->iw[j1] : 0.f;
+                    const T* gn = gb + (size_t)nn[u] * a.OH * a.OW * a.C;
+                    rg[u][0] = ld16(gn + (size_t)(i0 * a.OW + j0) * a.C);
+                    rg[u][1] = ld16(gn + (size_t)(i0 * a.OW + j1) * a.C);
+                    rg[u][2] = ld16(gn + (size_t)(i1 * a.OW + j0) * a.C);
+                    rg[u][3] = ld16(gn + (size_t)(i1 * a.OW + j1) * a.C);
+                    wg[u][0] = wh0 * ww0; wg[u][1] = wh0 * ww1; wg[u][2] = wh1 * ww0; wg[u][3] = wh1 * ww1;
+                }
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-                const int hbin = tabs->hb[hh[u]], wbin = tabs->wb[ww[u]];
-                for (int i = hbin & 0xffff; i <= (hbin >> 16); ++i)
-                    for (int j = wbin & 0xffff; j <= (wbin >> 16); ++j) {
+                for (int u = 0; u < U; ++u) {
+                    Chunk<T>::decode(rx[u], xf[u][0]);
+                    float acc[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
                         float g[EPC];
-                        Chunk<T>::decode(ld16(gb + (((size_t)nn[u] * a.OH + i) * a.OW + j) * a.C), g);
-                        const float wgt = tabs->ih[i] * tabs->iw[j];
+                        Chunk<T>::decode(rg[u][k], g);
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) acc[e] += g[e] * wgt;
+                        for (int e = 0; e < EPC; ++e) acc[e] += g[e] * wg[u][k];
                     }
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const float y = xf[u][0][e] * ch.sc[e] + ch.sf[e];
-                    dz[u][0][e] = y > 0.f ? acc[e] : 0.f;
+                    for (int e = 0; e < EPC; ++e) {
+                        const float y = xf[u][0][e] * ch.sc[e] + ch.sf[e];
+                        dz[u][0][e] = y > 0.f ? acc[e] : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    Chunk<T>::decode(rx[u], xf[u][0]);
+                    float acc[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+                    const int hbin = tabs->hb[hh[u]], wbin = tabs->wb[ww[u]];
+                    for (int i = hbin & 0xffff; i <= (hbin >> 16); ++i)
+                        for (int j = wbin & 0xffff; j <= (wbin >> 16); ++j) {
+                            float g[EPC];
+                            Chunk<T>::decode(ld16(gb + (((size_t)nn[u] * a.OH + i) * a.OW + j) * a.C), g);
+                            const float wgt = tabs->ih[i] * tabs->iw[j];
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) acc[e] += g[e] * wgt;
+                        }
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float y = xf[u][0][e] * ch.sc[e] + ch.sf[e];
+                        dz[u][0][e] = y > 0.f ? acc[e] : 0.f;
+                    }
                 }
             }
         } else {
