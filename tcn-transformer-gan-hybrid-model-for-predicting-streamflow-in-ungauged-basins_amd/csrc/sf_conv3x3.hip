@@ -284,16 +284,19 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     for (int i = 0; i < D_NWJ; ++i) {
         const int row = 16 * (wave + 8 * i) + jrow;          // t * 64 + k
         const int t = row >> 6, k = row & 63;
+        const int wch = jslot ^ ((row >> 2) & 3);                // channel chunk of the stage
         w_k[i] = k;
-        w_rel[i] = ((k * 9 + t) * p.C + ((jslot ^ ((row >> 2) & 3)) << 3)) * 2;   // bytes
+        w_rel[i] = ((k * 9 + t) * p.C + (wch << 3)) * 2;          // bytes
+        if ((wch << 3) >= p.C) w_rel[i] = -1;                    // C < 32: beyond the tensor -> zeros
     }
     int p_rel[D_NPJ], p_pyx[D_NPJ];
 #pragma unroll
     for (int i = 0; i < D_NPJ; ++i) {
         const int row = 16 * (wave + 8 * i) + jrow;          // patch pixel
         const int py = row / PW, px = row - py * PW;
-        p_pyx[i] = row < PP ? ((py << 16) | px) : -1;
-        p_rel[i] = ((py * p.W + px) * p.C + ((jslot ^ ((row >> 2) & 3)) << 3)) * 2;   // bytes
+        const int pch = jslot ^ ((row >> 2) & 3);
+        p_pyx[i] = (row < PP && (pch << 3) < p.C) ? ((py << 16) | px) : -1;
+        p_rel[i] = ((py * p.W + px) * p.C + (pch << 3)) * 2;   // bytes
     }
     const bf16* zsrc = reinterpret_cast<const bf16*>(&g_zero_chunk);
 
@@ -420,8 +423,35 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
             pv[c] = pin[c] && gy < p.H && gx < p.W;
             pixoff[c] = pv[c] ? (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo : 0;
         }
+        // mask operand: with K % 8 == 0 one 16-byte load per lane and group pair (the lane's
+        // pixel, group 2 gp + h), regrouped to the accumulator layout by two permlane32 swaps
         uint2 axr[2][2][4];
-        if (p.aux_mode) {
+        const bool wide_aux = (p.K & 7) == 0 && (p.ldo & 7) == 0;
+        if (p.aux_mode && wide_aux) {
+            uint4 ax4[2][2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
+                        const bf16* src = (pv[c] && k < p.K) ? p.aux + pixoff[c] + k : zsrc;
+                        ax4[c][a][gp] = *reinterpret_cast<const uint4*>(src);
+                    }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const uint4 d = ax4[c][a][gp];
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(d.x, d.z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(d.y, d.w, false, false);
+                        axr[c][a][2 * gp] = make_uint2(s0[0], s1[0]);
+                        axr[c][a][2 * gp + 1] = make_uint2(s0[1], s1[1]);
+                    }
+        } else if (p.aux_mode) {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -433,45 +463,77 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
                         axr[c][a][g] = *reinterpret_cast<const uint2*>(src);
                     }
         }
+        // bias / activation / mask for the four channels k .. k+3 this lane holds of group g
+        auto finish = [&](int c, int a, int g, float* v) {
+            const int k = it.k0 + a * 32 + 8 * g + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[a][c][4 * g + e];
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(sbias + (k < p.K ? k : 0));
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (p.act == SF_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else if (p.act == SF_ACT_LRELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+            }
+            if (p.aux_mode) {
+                const float neg = p.aux_mode == 1 ? 0.f : 0.2f;
+                const unsigned u0 = axr[c][a][g].x, u1 = axr[c][a][g].y;
+                // bf16 > 0  <=>  sign clear and not zero
+                const bool p0 = !(u0 & 0x8000u) && (u0 & 0x7fffu), p1 = !(u0 & 0x80000000u) && (u0 & 0x7fff0000u);
+                const bool p2 = !(u1 & 0x8000u) && (u1 & 0x7fffu), p3 = !(u1 & 0x80000000u) && (u1 & 0x7fff0000u);
+                v[0] = p0 ? v[0] : neg * v[0]; v[1] = p1 ? v[1] : neg * v[1];
+                v[2] = p2 ? v[2] : neg * v[2]; v[3] = p3 ? v[3] : neg * v[3];
+            }
+        };
+        auto pack2 = [](float x, float y) {
+            typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 t;
+            t[0] = (bf16)x; t[1] = (bf16)y;
+            return *reinterpret_cast<const unsigned*>(&t);
+        };
+        // bf16 output with K % 8 == 0: lanes l and l + 32 hold the two 4-channel halves of every
+        // 8-channel group of the same pixel; one v_permlane32_swap per dword regroups them so that
+        // the low lane owns all 8 channels of the even group and the high lane those of the odd
+        // group -> 16-byte stores instead of 8-byte ones.
+        const bool wide = p.out_dtype == SF_BF16 && (p.K & 7) == 0 && (p.ldo & 7) == 0;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int k = it.k0 + a * 32 + 8 * g + 4 * h;
-                    float v[4];
+                for (int gp = 0; gp < 2; ++gp) {
+                    float v0[4], v1[4];
+                    finish(c, a, 2 * gp, v0);
+                    finish(c, a, 2 * gp + 1, v1);
+                    if (wide) {
+                        const unsigned A0 = pack2(v0[0], v0[1]), A1 = pack2(v0[2], v0[3]);
+                        const unsigned B0 = pack2(v1[0], v1[1]), B1 = pack2(v1[2], v1[3]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
+                        const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
+                        if (pv[c] && k < p.K)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.out) + pixoff[c] + k) =
+                                make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[a][c][4 * g + e];
-                    if (p.bias) {
-                        const float4 bv = *reinterpret_cast<const float4*>(sbias + (k < p.K ? k : 0));
-                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                    }
-                    if (p.act == SF_ACT_RELU) {
+                        for (int q = 0; q < 2; ++q) {
+                            const float* v = q ? v1 : v0;
+                            const int k = it.k0 + a * 32 + 8 * (2 * gp + q) + 4 * h;
+                            if (pv[c] && k < p.K) {
+                                const long long off = pixoff[c] + k;
+                                if (p.out_dtype == SF_F32) {
+                                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + off) = make_float4(v[0], v[1], v[2], v[3]);
+                                } else {
+                                    Vec4<bf16> o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                    } else if (p.act == SF_ACT_LRELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-                    }
-                    if (p.aux_mode) {
-                        const float neg = p.aux_mode == 1 ? 0.f : 0.2f;
-                        const unsigned u0 = axr[c][a][g].x, u1 = axr[c][a][g].y;
-                        // bf16 > 0  <=>  sign clear and not zero
-                        const bool p0 = !(u0 & 0x8000u) && (u0 & 0x7fffu), p1 = !(u0 & 0x80000000u) && (u0 & 0x7fff0000u);
-                        const bool p2 = !(u1 & 0x8000u) && (u1 & 0x7fffu), p3 = !(u1 & 0x80000000u) && (u1 & 0x7fff0000u);
-                        v[0] = p0 ? v[0] : neg * v[0]; v[1] = p1 ? v[1] : neg * v[1];
-                        v[2] = p2 ? v[2] : neg * v[2]; v[3] = p3 ? v[3] : neg * v[3];
-                    }
-                    if (pv[c] && k < p.K) {
-                        const long long off = pixoff[c] + k;
-                        if (p.out_dtype == SF_F32) {
-                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + off) = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
-                            Vec4<bf16> o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o.set(e, v[e]);
-                            o.store(reinterpret_cast<bf16*>(p.out) + off);
+                                    for (int e = 0; e < 4; ++e) o.set(e, v[e]);
+                                    o.store(reinterpret_cast<bf16*>(p.out) + off);
+                                }
+                            }
                         }
                     }
                 }
@@ -557,7 +619,7 @@ int launch3_dma(const C3Params& q, hipStream_t s) {
     }
     p.ntiles = (int)ntiles;
     p.ktiles = (p.K + D_KT - 1) / D_KT;
-    p.nchunks = p.C / 32;
+    p.nchunks = (p.C + 31) / 32;
     const size_t lds = 2 * (size_t)D_BUF + sizeof(float) * D_BIAS_MAX;
     static bool attr_set = false;
     if (!attr_set) {
@@ -634,7 +696,7 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
     p.tiles_x = (W + p.TW - 1) / p.TW;
     p.tiles_y = (H + p.TH - 1) / p.TH;
     hipStream_t s = (hipStream_t)stream;
-    if (C % 32 == 0 && K <= D_BIAS_MAX && !getenv("SF_CONV3_OLD")) return launch3_dma(p, s);
+    if ((C % 32 == 0 || C == 16) && K <= D_BIAS_MAX && !getenv("SF_CONV3_OLD")) return launch3_dma(p, s);
     if (K <= 64 && C % 32 == 0) {
         p.ktiles = (K + 63) / 64;
         return launch3<64, 32>(p, s);

@@ -18,7 +18,6 @@
 //   3x3: waves = (k half, c half) x (even / odd reduction steps), 9 accumulator tiles each.
 //   4x4: waves = (k half, c half) x (taps 0-7 / 8-15), 8 accumulator tiles each.
 #include "sf_common.h"
-#include <cstdlib>
 #include "../../include/sfhip.h"
 
 namespace {
@@ -37,7 +36,7 @@ struct WPParams {
     float* ws;
     int N, IH, IW, OH, OW, Kd, Cx;
     int TH, TW, tiles_x, tiles_y, ntiles, tiles_per_slice;
-    int kt_tiles, ct_tiles, K64, C64, nslices, dbg;
+    int kt_tiles, ct_tiles, K64, C64, nslices;
 };
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_tr_p;
@@ -373,12 +372,13 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
         }
     };
 
+    const bool wave_idle = kt * 64 + kb * 32 >= p.Kd || ct * 64 + cb * 32 >= p.Cx;
     // One tile: start the DMA of the next tile into `fill`, run the MFMAs on `cur`.  The two
     // buffers are handed over as restrict pointers so that the compiler knows the reads of
     // `cur` cannot touch the DMA's destination (otherwise it drains the DMA before every read).
     auto tile_body = [&](const char* __restrict__ cur, char* __restrict__ fill, int next_tile) {
-        if (next_tile < p.ntiles && !(p.dbg & 1)) issue_tile(next_tile, fill);
-        if (p.dbg & 2) return;
+        if (next_tile < p.ntiles) issue_tile(next_tile, fill);
+        if (wave_idle) return;  // this wave's 32 x 32 block lies entirely in the channel padding
         if (grp == 0) run_steps(IntC<5>{}, cur + aOff, cur + bOff);
         else run_steps(IntC<4>{}, cur + aOff, cur + bOff);
     };
@@ -530,7 +530,6 @@ int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t
     int nslices = slices_for(K, Cin);
     if (nslices > p.ntiles) nslices = p.ntiles;
     p.nslices = nslices;
-    p.dbg = getenv("SF_WGRAD_DBG") ? atoi(getenv("SF_WGRAD_DBG")) : 0;
     p.tiles_per_slice = 0;
     const size_t lds = 2 * (size_t)G_BUF;
     static bool attr_set = false;

@@ -5,9 +5,11 @@ pkg = importlib.import_module("tcn-transformer-gan-hybrid-model-for-predicting-s
 ops = pkg.ops
 torch.manual_seed(0)
 N, H, W = 32, 400, 400
-for (C, K) in ((256, 64), (64, 256), (64, 64), (128, 256)):
+for (C, K) in ((256, 64), (64, 256), (64, 64), (128, 256), (16, 128)):
     if (C, K) == (128, 256):
         N, H, W = 160, 100, 100
+    if (C, K) == (16, 128):
+        N, H, W = 160, 200, 200
     x = torch.randn(N, H, W, C, device="cuda").bfloat16()
     wp = (torch.randn(K, 9, C, device="cuda") * 0.05).bfloat16()
     out = torch.empty(N, H, W, K, device="cuda", dtype=torch.bfloat16)
