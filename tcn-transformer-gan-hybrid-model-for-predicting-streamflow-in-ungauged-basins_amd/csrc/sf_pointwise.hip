@@ -221,6 +221,57 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ src, T* __restrict
     }
 }
 
+// Upsampling by >= 7x along x: a thread produces a strip of 8 consecutive output pixels of one
+// row for one 8-channel group.  The strip touches at most 3 source columns, so the thread loads
+// 2 rows x 3 columns once (12 16-byte loads, issued together), interpolates vertically once per
+// column and horizontally per output.  32-bit indices.
+template <typename T>
+__global__ void bilinear_up_strip_kernel(const float* __restrict__ src, T* __restrict__ dst, unsigned total, int C,
+                                         int h, int w, int OH, int OW) {
+    constexpr int XS = 8;
+    const int G = C / 8;
+    const unsigned strips = (OW + XS - 1) / XS;
+    for (unsigned o = blockIdx.x * NT + threadIdx.x; o < total; o += gridDim.x * NT) {
+        const unsigned cg = o % G;
+        unsigned r = o / G;
+        const unsigned st = r % strips; r /= strips;
+        const unsigned oy = r % OH, b = r / OH;
+        const int ox0 = st * XS;
+        const AxisW ay = axis_w(oy, h, OH);
+        AxisW ax[XS];
+#pragma unroll
+        for (int k = 0; k < XS; ++k) ax[k] = axis_w(ox0 + k < OW ? ox0 + k : OW - 1, w, OW);
+        const int c0 = ax[0].i0;
+        const float* base = src + ((size_t)b * h * w) * C + cg * 8;
+        float4 p[2][3][2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const int col = c0 + cc < w ? c0 + cc : w - 1;
+                const float* q = base + ((size_t)(rr ? ay.i1 : ay.i0) * w + col) * C;
+                p[rr][cc][0] = *reinterpret_cast<const float4*>(q);
+                p[rr][cc][1] = *reinterpret_cast<const float4*>(q + 4);
+            }
+        // keep the reference's association: ly0*(lx0*a00 + lx1*a01) + ly1*(lx0*a10 + lx1*a11)
+#pragma unroll
+        for (int k = 0; k < XS; ++k) {
+            if (ox0 + k >= OW) break;
+            const int d0 = ax[k].i0 - c0, d1 = ax[k].i1 - c0;
+            float out[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a00 = d0 == 0 ? (&p[0][0][e >> 2].x)[e & 3] : d0 == 1 ? (&p[0][1][e >> 2].x)[e & 3] : (&p[0][2][e >> 2].x)[e & 3];
+                const float a01 = d1 == 0 ? (&p[0][0][e >> 2].x)[e & 3] : d1 == 1 ? (&p[0][1][e >> 2].x)[e & 3] : (&p[0][2][e >> 2].x)[e & 3];
+                const float a10 = d0 == 0 ? (&p[1][0][e >> 2].x)[e & 3] : d0 == 1 ? (&p[1][1][e >> 2].x)[e & 3] : (&p[1][2][e >> 2].x)[e & 3];
+                const float a11 = d1 == 0 ? (&p[1][0][e >> 2].x)[e & 3] : d1 == 1 ? (&p[1][1][e >> 2].x)[e & 3] : (&p[1][2][e >> 2].x)[e & 3];
+                out[e] = ay.l0 * (ax[k].l0 * a00 + ax[k].l1 * a01) + ay.l1 * (ax[k].l0 * a10 + ax[k].l1 * a11);
+            }
+            store_chunk<T>(dst + (((size_t)b * OH + oy) * OW + ox0 + k) * C + cg * 8, out);
+        }
+    }
+}
+
 // pass 1: tmp[b][oy][sx][c] = sum_ox wx(ox -> sx) * ddst[b][oy][ox][c]
 template <typename T>
 __global__ void bilinear_bwd_x_kernel(const T* __restrict__ ddst, float* __restrict__ tmp, int B, int C, int w,
@@ -240,14 +291,21 @@ __global__ void bilinear_bwd_x_kernel(const T* __restrict__ ddst, float* __restr
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-        for (int ox = lo; ox <= hi; ++ox) {
-            const AxisW a = axis_w(ox, w, OW);
-            const float wt = (a.i0 == sx ? a.l0 : 0.f) + (a.i1 == sx ? a.l1 : 0.f);
-            if (wt == 0.f) continue;
-            float f[EPC];
-            load_chunk<T>(ddst + (r * OW + ox) * C + cg * EPC, f);
+        // batches of 4 unconditional loads (clamped column, weight 0 past the end)
+        for (int ox = lo; ox <= hi; ox += 4) {
+            float f[4][EPC], wt[4];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[e] += wt * f[e];
+            for (int u = 0; u < 4; ++u) {
+                const int oc = ox + u <= hi ? ox + u : hi;
+                const AxisW a = axis_w(oc, w, OW);
+                const float wv = (a.i0 == sx ? a.l0 : 0.f) + (a.i1 == sx ? a.l1 : 0.f);
+                wt[u] = ox + u <= hi ? wv : 0.f;
+                load_chunk<T>(ddst + (r * OW + oc) * C + cg * EPC, f[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += wt[u] * f[u][e];
         }
 #pragma unroll
         for (int q = 0; q < EPC; q += 4)
@@ -386,6 +444,13 @@ extern "C" int sf_bilinear_fwd(const void* src, int src_dtype, void* dst, int dt
     SF_REQUIRE(src_dtype == SF_F32, "sf_bilinear_fwd: source must be NHWC f32");
     SF_REQUIRE(C == Cpad && Cpad % (dtype == SF_BF16 ? 8 : 4) == 0, "sf_bilinear_fwd: C=%d must equal Cpad and be a chunk multiple", C);
     const int epc = dtype == SF_BF16 ? 8 : 4;
+    if (dtype == SF_BF16 && OW >= 7 * w && (long long)B * OH * ((OW + 7) / 8) * (C / 8) < 0x7fffffffLL) {
+        const long long items = (long long)B * OH * ((OW + 7) / 8) * (C / 8);
+        hipLaunchKernelGGL(bilinear_up_strip_kernel<bf16>, dim3(grid_for(items, 16384)), dim3(NT), 0, (hipStream_t)stream,
+                           (const float*)src, (bf16*)dst, (unsigned)items, C, h, w, OH, OW);
+        SF_LAUNCH_CHECK("sf_bilinear_fwd");
+        return SF_OK;
+    }
     const long long total = (long long)B * OH * OW * (C / epc);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(grid_for(total, 16384)), dim3(NT), 0,
                                          (hipStream_t)stream, (const float*)src, (T*)dst, B, C, h, w, OH, OW));
