@@ -1,6 +1,8 @@
-// 3x3 stride-1 convolution (forward and data gradient) for bf16 NHWC tensors.
+// 3x3 stride-1 convolution (forward and data gradient) for bf16 NHWC tensors.  Two kernels:
+// conv3_dma_kernel (persistent workgroups, buffer-load-to-LDS stages; C % 32 == 0 or C == 16)
+// and, for other channel counts, the register-staged conv3x3_kernel described first.
 //
-// A workgroup owns a TH x TW tile of output pixels (TH*TW <= 256) and a tile of KT output
+// conv3x3_kernel: a workgroup owns a TH x TW tile of output pixels (TH*TW <= 256) and a tile of KT output
 // channels.  Per chunk of CK input channels it stages, once, the (TH+2) x (TW+2) halo patch of
 // the input and the weights of all nine taps in LDS; the nine taps then read their B operand
 // from the same patch at shifted pixel positions, so every input element crosses L2 -> LDS
@@ -9,7 +11,6 @@
 // chunk (latency hidden behind compute; a second resident workgroup covers the LDS store
 // burst).  D is kept as [kout][pixel] so a lane stores 4 consecutive channels per access.
 #include "sf_common.h"
-#include <cstdlib>
 #include "../../include/sfhip.h"
 
 namespace {
@@ -245,7 +246,7 @@ struct C3DParams {
     void* out;
     int N, H, W, C, K, ldo;
     int TH, TW, tiles_x, tiles_y, ntiles, ktiles, nchunks;
-    int act, aux_mode, out_dtype, dbg;
+    int act, aux_mode, out_dtype;
     int dy[9], dx[9];
 };
 
@@ -564,10 +565,10 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     advance(nxt);
     // one step of the pipeline; `cur_buf` holds the landed stage, `fill` takes the next copy
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
-        const StageSrc ss = stage_src(nxt, nxt.q < nitems && !(p.dbg & 1));
+        const StageSrc ss = stage_src(nxt, nxt.q < nitems);
         run_stage(cur_buf, fill, ss);
         if (cur.chunk == p.nchunks - 1) {
-            if (!(p.dbg & 4)) epilogue(cur);
+            epilogue(cur);
             zero_acc();
         }
         cur = nxt;
@@ -607,7 +608,6 @@ int launch3_dma(const C3Params& q, hipStream_t s) {
     p.N = q.N; p.H = q.H; p.W = q.W; p.C = q.C; p.K = q.K; p.ldo = q.ldo;
     p.act = q.act; p.aux_mode = q.aux_mode; p.out_dtype = q.out_dtype;
     for (int t = 0; t < 9; ++t) { p.dy[t] = q.dy[t]; p.dx[t] = q.dx[t]; }
-    p.dbg = getenv("SF_C3_DBG") ? atoi(getenv("SF_C3_DBG")) : 0;
     pick_tile_dma(p.H, p.W, &p.TH, &p.TW);
     p.tiles_x = (p.W + p.TW - 1) / p.TW;
     p.tiles_y = (p.H + p.TH - 1) / p.TH;
@@ -696,7 +696,7 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
     p.tiles_x = (W + p.TW - 1) / p.TW;
     p.tiles_y = (H + p.TH - 1) / p.TH;
     hipStream_t s = (hipStream_t)stream;
-    if ((C % 32 == 0 || C == 16) && K <= D_BIAS_MAX && !getenv("SF_CONV3_OLD")) return launch3_dma(p, s);
+    if ((C % 32 == 0 || C == 16) && K <= D_BIAS_MAX) return launch3_dma(p, s);
     if (K <= 64 && C % 32 == 0) {
         p.ktiles = (K + 63) / 64;
         return launch3<64, 32>(p, s);
