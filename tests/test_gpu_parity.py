@@ -475,6 +475,41 @@ def test_wgrad3x3_matches_generic(sf):
         close(dw_a, ref.numpy(), 1e-4)
 
 
+def test_conv3x3_kernels_against_f32_conv(sf):
+    """sf_conv3x3 (persistent DMA kernel for C % 32 == 0 or C == 16, register-staged kernel for
+    other multiples of 16) forward with bias + ReLU and data gradient with a ReLU mask, against
+    an f32 conv on the same bf16 operands.  Odd sizes, partial tiles, K not a multiple of 64,
+    a single-pixel-row image.  Stated tolerance: 1e-2 of the output's max (bf16 output rounding)."""
+    ops = sf.ops
+    torch.manual_seed(3)
+    cases = [(2, 37, 53, 16, 24), (1, 100, 100, 64, 64), (3, 20, 61, 32, 136), (2, 9, 200, 48, 72),
+             (1, 1, 70, 96, 8), (2, 33, 33, 256, 64)]
+    for (N, H, W, C, K) in cases:
+        x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(K, C, 3, 3, device=DEV) * (1.0 / (3.0 * C ** 0.5))).to(torch.bfloat16).float()
+        b = torch.randn(K, device=DEV)
+        Kp = (K + 7) // 8 * 8
+        wp = ops.pack_conv_weight(w.contiguous(), torch.bfloat16, list(range(9)), False, K, C)
+        out = torch.zeros(N, H, W, Kp, device=DEV, dtype=torch.bfloat16)
+        ops.conv3x3(x, wp, out, K, bias=b, act=ops.ACT_RELU)
+        ref = torch.relu(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2).cpu(), w.cpu(), b.cpu(), padding=1))
+        close(out[..., :K].float().permute(0, 3, 1, 2), ref.numpy(), 1e-2)
+        if Kp > K:
+            assert float(out[..., K:].float().abs().max()) == 0.0   # padding channels untouched
+        # data gradient wrt x of conv(x) given dz, masked by (mask > 0)
+        dz = torch.randn(N, H, W, Kp, device=DEV).to(torch.bfloat16)
+        dz[..., K:] = 0
+        mask = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+        wT = ops.pack_conv_weight(w.contiguous(), torch.bfloat16, list(range(9)), True, C, Kp)
+        dx = torch.empty(N, H, W, C, device=DEV, dtype=torch.bfloat16)
+        if Kp % 16 == 0:
+            ops.conv3x3(dz, wT, dx, C, dgrad=True, aux=mask, aux_mode=1)
+            refdx = torch.nn.grad.conv2d_input((N, C, H, W), w.cpu(), dz[..., :K].float().permute(0, 3, 1, 2).cpu(),
+                                               padding=1)
+            refdx = refdx * (mask.float().permute(0, 3, 1, 2).cpu() > 0)
+            close(dx.float().permute(0, 3, 1, 2), refdx.numpy(), 1e-2)
+
+
 def test_wgrad4x4s2_matches_reference(sf):
     """Stride-2 4x4 weight gradient (PatchGAN layers) against torch's f32 conv2d_weight on the
     same bf16 operands: odd / even input sizes, partial tiles, several channel tiles."""
