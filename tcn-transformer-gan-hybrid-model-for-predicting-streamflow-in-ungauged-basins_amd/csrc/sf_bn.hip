@@ -575,7 +575,9 @@ static int colsum_launch(const char* who, bool sq, const void* x, int dtype, lon
     }
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const int rpp = BT / (C / epc);
-    const Split sp = split_rows(M, rpp * 8, 512);
+    // few workgroups: every one ends with a same-address atomic per channel (~0.1 us each,
+    // serialised), and 128 x 512 threads already stream at full rate
+    const Split sp = split_rows(M, rpp * 8, 128);
     if (sq) {
         DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, true>), dim3(sp.grid), dim3(BT), 0, s, (const T*)x,
                                              (unsigned)M, sp.per, C, ws));
@@ -660,7 +662,7 @@ extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* 
                                 int W, int C, int Creal, int OH, int OW, void* stream) {
     BnBwd a;
     const int grid = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, scale, N, H, W, C, Creal, OH, OW, 1, dtype,
-                                dy_dtype, 512);
+                                dy_dtype, 128);
     if (grid < 0) return grid;
     SF_REQUIRE(ws, "sf_bn_bwd_reduce: null workspace");
     hipStream_t s = (hipStream_t)stream;

@@ -731,7 +731,7 @@ extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, f
     const long long M = (long long)N * OH * OW;
     SF_REQUIRE(M < 0x7fffffffLL, "sf_dconv1_bwd_weight: too many pixels");
     const int step = rpp * 4;
-    long long grid = (M + step - 1) / step; if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+    long long grid = (M + step - 1) / step; if (grid > 256) grid = 256; if (grid < 1) grid = 1;
     long long per = ((M + grid - 1) / grid + step - 1) / step * step;
     grid = (M + per - 1) / per;
     DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_bwd_weight_kernel<T>, dim3((unsigned)grid), dim3(NT), 0, s, x,
@@ -835,7 +835,7 @@ extern "C" int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, 
     const long long M = (long long)N * OH * OW;
     int grid = (int)((M + rpp * 16 - 1) / (rpp * 16)); if (grid > 256) grid = 256; if (grid < 1) grid = 1;
     if (pw1_ok(dtype, C, R, pad, M)) {
-        const RowSplit sp = split_rows_small(M, rpp * 8, 1024);
+        const RowSplit sp = split_rows_small(M, rpp * 8, 256);
         DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_bwd_weight_kernel<T>, dim3(sp.grid), dim3(NT), 0, s, (const T*)x, dy, dw,
                                              db, (unsigned)M, sp.per, C, Creal));
         SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
