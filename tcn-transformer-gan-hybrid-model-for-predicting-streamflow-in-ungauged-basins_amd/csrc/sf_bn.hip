@@ -533,8 +533,11 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply_kernel(BnBwd a, const double*
 
 // rows per workgroup for `items` rows on at most `cap` workgroups, a multiple of `step`
 struct Split { unsigned per; int grid; };
-inline Split split_rows(long long items, int step, int cap) {
-    long long grid = (items + step - 1) / step;
+// min_batches > 1 (reductions): a workgroup gets at least that many batches, so small tensors
+// use few workgroups -- each workgroup of a reduction ends with one same-address atomic per
+// channel, ~0.1 us apiece and serialised.
+inline Split split_rows(long long items, int step, int cap, int min_batches = 1) {
+    long long grid = (items + (long long)step * min_batches - 1) / ((long long)step * min_batches);
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     long long per = (items + grid - 1) / grid;
@@ -575,9 +578,7 @@ static int colsum_launch(const char* who, bool sq, const void* x, int dtype, lon
     }
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const int rpp = BT / (C / epc);
-    // few workgroups: every one ends with a same-address atomic per channel (~0.1 us each,
-    // serialised), and 128 x 512 threads already stream at full rate
-    const Split sp = split_rows(M, rpp * 8, 128);
+    const Split sp = split_rows(M, rpp * 8, 512, 16);
     if (sq) {
         DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, true>), dim3(sp.grid), dim3(BT), 0, s, (const T*)x,
                                              (unsigned)M, sp.per, C, ws));
@@ -651,7 +652,7 @@ static int fill_bnbwd(BnBwd& a, int mode, const void* x, const void* dy, const f
     a.N = N; a.H = H; a.W = W; a.C = C; a.Creal = Creal; a.OH = OH; a.OW = OW; a.training = training;
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const long long items = mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
-    const Split sp = split_rows(items, (BT / (C / epc)) * (mode == 0 ? 2 : 4), cap);
+    const Split sp = split_rows(items, (BT / (C / epc)) * (mode == 0 ? 2 : 4), cap, cap <= 512 ? 32 : 1);
     a.items = (unsigned)items;
     a.per = sp.per;
     return sp.grid;
@@ -662,7 +663,7 @@ extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* 
                                 int W, int C, int Creal, int OH, int OW, void* stream) {
     BnBwd a;
     const int grid = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, scale, N, H, W, C, Creal, OH, OW, 1, dtype,
-                                dy_dtype, 128);
+                                dy_dtype, 512);
     if (grid < 0) return grid;
     SF_REQUIRE(ws, "sf_bn_bwd_reduce: null workspace");
     hipStream_t s = (hipStream_t)stream;
