@@ -66,7 +66,7 @@ struct KParams {
     const float* bias;
     const void* aux;
     long long I, J, R, lda, ldb, ldo;
-    int niters, iters_per_split, nsplit, ni_tiles, nj_tiles;
+    int niters, iters_per_split, nsplit, nsplit_req, ni_tiles, nj_tiles;
     int b_gather, out_mode, out_dtype, act, aux_mode, atomic;
     unsigned long long dy_pack, dx_pack;  // tap offsets + 8, 4 bits per tap
     sf_conv_geom g;
@@ -91,11 +91,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
 }
 
-template <typename T, bool A_KM, bool B_KM, int TI>
+template <typename T, bool A_KM, bool B_KM, int TI, int BK = Mma<T>::BK>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
     using M = Mma<T>;
     constexpr int EPC = ElemTraits<T>::EPC;
-    constexpr int BK = M::BK;
     constexpr int LDA = A_KM ? (TI + M::PAD_KM) : (BK + M::PAD_RM);
     constexpr int LDB = B_KM ? (TJ + M::PAD_KM) : (BK + M::PAD_RM);
     constexpr int A_ELEMS = A_KM ? BK * LDA : TI * LDA;
@@ -112,7 +111,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
     constexpr int NT = 2;        // along j
     static_assert(A_CHUNKS % NTHREADS == 0 || A_CHUNKS < NTHREADS, "tile/threads mismatch");
 
-    __shared__ __attribute__((aligned(16))) T smem[2 * (A_ELEMS + B_ELEMS)];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);  // 2 * (A_ELEMS + B_ELEMS) elements
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
@@ -396,24 +396,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
     }
 }
 
-template <typename T, bool A_KM, bool B_KM>
-int launch(const KParams& p, hipStream_t s) {
-    const int TIsel = p.I <= 64 ? 64 : 128;
-    KParams q = p;
-    q.ni_tiles = ceil_div(p.I, TIsel);
-    q.nj_tiles = ceil_div(p.J, TJ);
-    const long long nblk = (long long)q.ni_tiles * q.nj_tiles * q.nsplit;
+template <typename T, bool A_KM, bool B_KM, int TI, int BK>
+int launch_one(const KParams& q, hipStream_t s) {
+    using M = Mma<T>;
+    constexpr int LDA = A_KM ? (TI + M::PAD_KM) : (BK + M::PAD_RM);
+    constexpr int LDB = B_KM ? (TJ + M::PAD_KM) : (BK + M::PAD_RM);
+    constexpr size_t lds = sizeof(T) * 2 * ((A_KM ? BK * LDA : TI * LDA) + (B_KM ? BK * LDB : TJ * LDB));
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, A_KM, B_KM, TI, BK>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                sf_set_error("sf_gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
+                return SF_ELAUNCH;
+            }
+            attr_set = true;
+        }
+    }
+    KParams p = q;
+    p.niters = ceil_div(p.R, BK);
+    p.nsplit = p.nsplit_req > p.niters ? p.niters : p.nsplit_req;
+    p.iters_per_split = ceil_div(p.niters, p.nsplit);
+    p.nsplit = ceil_div(p.niters, p.iters_per_split);
+    p.ni_tiles = ceil_div(p.I, TI);
+    p.nj_tiles = ceil_div(p.J, TJ);
+    const long long nblk = (long long)p.ni_tiles * p.nj_tiles * p.nsplit;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         sf_set_error("sf_gemm: bad grid (%lld blocks)", nblk);
         return SF_EINVAL;
     }
-    dim3 grid((unsigned)nblk), block(NTHREADS);
-    if (TIsel == 64)
-        hipLaunchKernelGGL((gemm_kernel<T, A_KM, B_KM, 64>), grid, block, 0, s, q);
-    else
-        hipLaunchKernelGGL((gemm_kernel<T, A_KM, B_KM, 128>), grid, block, 0, s, q);
+    hipLaunchKernelGGL((gemm_kernel<T, A_KM, B_KM, TI, BK>), dim3((unsigned)nblk), dim3(NTHREADS), lds, s, p);
     SF_LAUNCH_CHECK("sf_gemm");
     return SF_OK;
+}
+
+template <typename T, bool A_KM, bool B_KM>
+int launch(const KParams& p, hipStream_t s) {
+    constexpr int BK0 = Mma<T>::BK;
+    // (a 64-deep reduction step was measured slower for the PatchGAN shapes: its 72 KB of LDS
+    // leave one or two workgroups per CU and the exposed latency outweighs the saved barriers)
+    if (p.I <= 64) return launch_one<T, A_KM, B_KM, 64, BK0>(p, s);
+    return launch_one<T, A_KM, B_KM, 128, BK0>(p, s);
 }
 
 template <typename T> int dispatch(const sf_gemm_desc* d, const KParams& p, hipStream_t s) {
@@ -472,10 +495,8 @@ extern "C" int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, cons
     KParams p;
     p.A = A; p.B = B; p.out = out; p.bias = bias; p.aux = aux;
     p.I = d->I; p.J = d->J; p.R = d->R; p.lda = d->lda; p.ldb = d->ldb; p.ldo = d->ldo;
-    p.niters = ceil_div(d->R, bk);
-    p.nsplit = d->nsplit > p.niters ? p.niters : d->nsplit;
-    p.iters_per_split = ceil_div(p.niters, p.nsplit);
-    p.nsplit = ceil_div(p.niters, p.iters_per_split);
+    p.niters = p.iters_per_split = p.nsplit = 0;   // set per kernel variant in launch_one
+    p.nsplit_req = d->nsplit;
     p.ni_tiles = p.nj_tiles = 0;
     p.b_gather = d->b_gather; p.out_mode = d->out_mode; p.out_dtype = d->out_dtype;
     p.act = d->act; p.aux_mode = d->aux_mode; p.g = d->g;
