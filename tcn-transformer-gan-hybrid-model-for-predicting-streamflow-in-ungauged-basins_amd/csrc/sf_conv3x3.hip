@@ -227,13 +227,25 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_kernel(C3Params p) {
 // ds_read_b128 address, which spreads the 16 rows of a read group over all 64 banks.
 // Items are dealt so that the workgroups of one XCD work on the same few tiles at a time
 // (different output-channel blocks): the shared input patches are L2 hits.
-constexpr int D_TP = 512, D_PP = 640, D_KT = 64, D_NT = 512;
-constexpr int D_WIMG = 9 * D_KT * 64;          // 36,864 bytes
-constexpr int D_PIMG = D_PP * 64;              // 40,960 bytes
-constexpr int D_BUF = D_WIMG + D_PIMG;         // 77,824 bytes; two buffers = 155,648
+//
+// Two shapes of the same kernel: <KT = 64 output channels, CK = 32 input channels per stage>
+// (64-byte rows, slot ^= (row >> 2) & 3) and, for K >= 128 or C % 32 != 0, <KT = 128, CK = 16>
+// (32-byte rows, slot ^= (row >> 3) & 1): the wide shape fetches 57 KB instead of 78 KB per 144
+// MFMAs per SIMD and reads each patch for half as many output-channel blocks.
+constexpr int D_TP = 512, D_PP = 640, D_NT = 512;
 constexpr int D_BIAS_MAX = 1024;                // output channels whose bias fits the LDS copy
-constexpr int D_WJOBS = D_WIMG / 1024, D_PJOBS = D_PIMG / 1024;
-constexpr int D_NWJ = (D_WJOBS + 7) / 8, D_NPJ = (D_PJOBS + 7) / 8;
+template <int KT, int CK> struct DCfg {
+    static constexpr int ROWB = CK * 2;                  // bytes per LDS row
+    static constexpr int SLOTS = ROWB / 16;              // 16-byte slots per row
+    static constexpr int RPP = 1024 / ROWB;              // rows per 1 KiB copy piece
+    static constexpr int WIMG = 9 * KT * ROWB;           // 36,864 bytes for both shapes
+    static constexpr int PIMG = D_PP * ROWB;             // 40,960 / 20,480 bytes
+    static constexpr int BUF = WIMG + PIMG;
+    static constexpr int WJOBS = WIMG / 1024, PJOBS = PIMG / 1024;
+    static constexpr int NWJ = (WJOBS + 7) / 8, NPJ = (PJOBS + 7) / 8;
+    static constexpr int MT = KT / 32, KS = CK / 16, NPOS = 9 * KS;
+    static __device__ __forceinline__ int swz(int row) { return SLOTS == 4 ? (row >> 2) & 3 : (row >> 3) & 1; }
+};
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -255,7 +267,12 @@ struct ItemPos {
     int n, y0, x0, k0;     // decoded item
 };
 
-__global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
+template <int KT, int CK>
+__device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
+    using Cf = DCfg<KT, CK>;
+    constexpr int ROWB = Cf::ROWB, SLOTS = Cf::SLOTS, RPP = Cf::RPP, MT = Cf::MT, KS = Cf::KS, NPOS = Cf::NPOS;
+    constexpr int D_WIMG = Cf::WIMG, D_BUF = Cf::BUF, D_WJOBS = Cf::WJOBS, D_PJOBS = Cf::PJOBS;
+    constexpr int D_NWJ = Cf::NWJ, D_NPJ = Cf::NPJ;
     extern __shared__ __attribute__((aligned(16))) char smd[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,19 +290,19 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
         const int rest = tile / p.tiles_x;
         const int ty = rest % p.tiles_y;
         it.n = rest / p.tiles_y;
-        it.y0 = ty * p.TH; it.x0 = tx * p.TW; it.k0 = kt * D_KT;
+        it.y0 = ty * p.TH; it.x0 = tx * p.TW; it.k0 = kt * KT;
     };
 
-    // ---- DMA jobs (tile-invariant part).  A job fills 16 consecutive 64-byte rows: lane l writes
-    // slot l & 3 of row l >> 2 and fetches the channel chunk (l & 3) ^ ((row >> 2) & 3).
-    const int jrow = lane >> 2, jslot = lane & 3;
+    // ---- DMA jobs (tile-invariant part).  A job fills RPP consecutive rows: lane l writes slot
+    // l % SLOTS of row l / SLOTS and fetches the channel chunk slot ^ swz(row).
+    const int jrow = lane / SLOTS, jslot = lane % SLOTS;
     int w_rel[D_NWJ], w_k[D_NWJ];
     (void)w_k;
 #pragma unroll
     for (int i = 0; i < D_NWJ; ++i) {
-        const int row = 16 * (wave + 8 * i) + jrow;          // t * 64 + k
-        const int t = row >> 6, k = row & 63;
-        const int wch = jslot ^ ((row >> 2) & 3);                // channel chunk of the stage
+        const int row = RPP * (wave + 8 * i) + jrow;         // t * KT + k
+        const int t = row / KT, k = row % KT;
+        const int wch = jslot ^ Cf::swz(row);                    // channel chunk of the stage
         w_k[i] = k;
         w_rel[i] = ((k * 9 + t) * p.C + (wch << 3)) * 2;          // bytes
         if ((wch << 3) >= p.C) w_rel[i] = -1;                    // C < 32: beyond the tensor -> zeros
@@ -293,9 +310,9 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     int p_rel[D_NPJ], p_pyx[D_NPJ];
 #pragma unroll
     for (int i = 0; i < D_NPJ; ++i) {
-        const int row = 16 * (wave + 8 * i) + jrow;          // patch pixel
+        const int row = RPP * (wave + 8 * i) + jrow;         // patch pixel
         const int py = row / PW, px = row - py * PW;
-        const int pch = jslot ^ ((row >> 2) & 3);
+        const int pch = jslot ^ Cf::swz(row);
         p_pyx[i] = (row < PP && (pch << 3) < p.C) ? ((py << 16) | px) : -1;
         p_rel[i] = ((py * p.W + px) * p.C + (pch << 3)) * 2;   // bytes
     }
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     // `live` false (nothing left to copy) makes both buffers empty: the pieces then write zeros
     // and touch no memory, and the MFMA loop needs no branch around them.
     auto stage_src = [&](const ItemPos& it, bool live) {
-        const int c0 = it.chunk * 32;
+        const int c0 = it.chunk * CK;
         const bf16* wbase = p.w + (size_t)it.k0 * 9 * p.C + c0;
         const bf16* ibase = p.in + (size_t)it.n * p.H * p.W * p.C + c0;
         const unsigned wbytes = live ? (unsigned)(((p.K - it.k0) * 9 * p.C - c0) * 2) : 0u;
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
         }
     };
 
-    // ---- compute mapping: wave = 64 pixels x 64 output channels (2 x 2 MFMA tiles)
+    // ---- compute mapping: wave = 64 pixels x KT output channels (MT x 2 MFMA tiles)
     int prow[2];           // patch row of the lane's pixel (centre tap)
     int lyx[2];
     bool pin[2];
@@ -355,23 +372,23 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
         lyx[c] = (ly << 16) | lx;
     }
     // byte offset of the lane's B fragment in the patch image for tap t, reduction step 0
-    // (step 1 is the same offset ^ 32): tile-invariant, so computed once
+    // (step 1, 64-byte rows only, is the same offset ^ 32): tile-invariant, so computed once
     int pa[2][9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int row = prow[c] + p.dy[t] * PW + p.dx[t];
-            pa[c][t] = (row << 6) + ((((row >> 2) & 3) ^ h) << 4);
+            pa[c][t] = row * ROWB + ((Cf::swz(row) ^ h) << 4);
         }
-    // weights: row = t*64 + a*32 + r, slot = (h + 2 ks) ^ ((r >> 2) & 3); one lane offset per ks
-    const int aLane0 = r * 64 + ((h ^ ((r >> 2) & 3)) << 4);
-    const int aLane1 = r * 64 + (((h + 2) ^ ((r >> 2) & 3)) << 4);
+    // weights: row = t*KT + a*32 + r, slot = (h + 2 ks) ^ swz(r); one lane offset per ks
+    const int aLane0 = r * ROWB + ((h ^ Cf::swz(r)) << 4);
+    const int aLane1 = r * ROWB + (((h + 2) ^ Cf::swz(r)) << 4);   // used by the 64-byte-row shape only
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -379,32 +396,33 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     };
     zero_acc();
 
-    // One stage: 9 taps x 2 reduction steps, the four fragment reads of position i + 1 issued
-    // before the four MFMAs of position i (pinned order, counted lgkmcnt).
+    // One stage: 9 taps x KS reduction steps, the MT + 2 fragment reads of position i + 1 issued
+    // before the 2 MT MFMAs of position i (pinned order, counted lgkmcnt).
     // One copy piece of the next stage is issued per position (an LDS-DMA instruction holds the
     // issuing wave for ~100 cycles; spread out, the other wave's MFMAs cover it).
     auto run_stage = [&](const char* __restrict__ cur, char* __restrict__ fill, const StageSrc& ss) {
         const char* wl0 = cur + aLane0;
         const char* wl1 = cur + aLane1;
         const char* pl = cur + D_WIMG;
-        bf16x8 fa[2][2], fb[2][2];
+        bf16x8 fa[2][MT], fb[2][2];
         auto issue = [&](int i) {
-            const int t = i >> 1, ks = i & 1, s = i & 1;
+            const int t = i / KS, ks = i % KS, s = i & 1;
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-                fa[s][a] = *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (t * 64 + a * 32) * 64);
+            for (int a = 0; a < MT; ++a)
+                fa[s][a] = *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (t * KT + a * 32) * ROWB);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
                 fb[s][c] = *reinterpret_cast<const bf16x8*>(pl + (pa[c][t] ^ (ks << 5)));
         };
+        static_assert(D_NWJ + D_NPJ <= NPOS, "one copy piece per position");
         issue(0);
 #pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            if (i + 1 < 18) issue(i + 1);
+        for (int i = 0; i < NPOS; ++i) {
+            if (i + 1 < NPOS) issue(i + 1);
             if (i < D_NWJ + D_NPJ) issue_piece(ss, fill, i);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][a], fb[i & 1][c], acc[a][c], 0, 0, 0);
@@ -424,93 +442,86 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
             pv[c] = pin[c] && gy < p.H && gx < p.W;
             pixoff[c] = pv[c] ? (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo : 0;
         }
-        // mask operand: with K % 8 == 0 one 16-byte load per lane and group pair (the lane's
-        // pixel, group 2 gp + h), regrouped to the accumulator layout by two permlane32 swaps
-        uint2 axr[2][2][4];
-        const bool wide_aux = (p.K & 7) == 0 && (p.ldo & 7) == 0;
-        if (p.aux_mode && wide_aux) {
-            uint4 ax4[2][2][2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
-                        const bf16* src = (pv[c] && k < p.K) ? p.aux + pixoff[c] + k : zsrc;
-                        ax4[c][a][gp] = *reinterpret_cast<const uint4*>(src);
-                    }
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        const uint4 d = ax4[c][a][gp];
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(d.x, d.z, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(d.y, d.w, false, false);
-                        axr[c][a][2 * gp] = make_uint2(s0[0], s1[0]);
-                        axr[c][a][2 * gp + 1] = make_uint2(s0[1], s1[1]);
-                    }
-        } else if (p.aux_mode) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int k = it.k0 + a * 32 + 8 * g + 4 * h;
-                        const bf16* src = (pv[c] && k < p.K) ? p.aux + pixoff[c] + k : zsrc;
-                        axr[c][a][g] = *reinterpret_cast<const uint2*>(src);
-                    }
-        }
-        // bias / activation / mask for the four channels k .. k+3 this lane holds of group g
-        auto finish = [&](int c, int a, int g, float* v) {
-            const int k = it.k0 + a * 32 + 8 * g + 4 * h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[a][c][4 * g + e];
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(sbias + (k < p.K ? k : 0));
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (p.act == SF_ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            } else if (p.act == SF_ACT_LRELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-            }
-            if (p.aux_mode) {
-                const float neg = p.aux_mode == 1 ? 0.f : 0.2f;
-                const unsigned u0 = axr[c][a][g].x, u1 = axr[c][a][g].y;
-                // bf16 > 0  <=>  sign clear and not zero
-                const bool p0 = !(u0 & 0x8000u) && (u0 & 0x7fffu), p1 = !(u0 & 0x80000000u) && (u0 & 0x7fff0000u);
-                const bool p2 = !(u1 & 0x8000u) && (u1 & 0x7fffu), p3 = !(u1 & 0x80000000u) && (u1 & 0x7fff0000u);
-                v[0] = p0 ? v[0] : neg * v[0]; v[1] = p1 ? v[1] : neg * v[1];
-                v[2] = p2 ? v[2] : neg * v[2]; v[3] = p3 ? v[3] : neg * v[3];
-            }
-        };
         auto pack2 = [](float x, float y) {
             typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
             bf16x2 t;
             t[0] = (bf16)x; t[1] = (bf16)y;
             return *reinterpret_cast<const unsigned*>(&t);
         };
-        // bf16 output with K % 8 == 0: lanes l and l + 32 hold the two 4-channel halves of every
-        // 8-channel group of the same pixel; one v_permlane32_swap per dword regroups them so that
-        // the low lane owns all 8 channels of the even group and the high lane those of the odd
-        // group -> 16-byte stores instead of 8-byte ones.
-        const bool wide = p.out_dtype == SF_BF16 && (p.K & 7) == 0 && (p.ldo & 7) == 0;
+        // bf16 tensors with K % 8 == 0 use 16-byte accesses: lanes l and l + 32 hold the two
+        // 4-channel halves of every 8-channel group of the same pixel; one v_permlane32_swap per
+        // dword regroups them so that the low lane owns all 8 channels of the even group and the
+        // high lane those of the odd group (stores), and back (mask loads).
+        const bool wide = (p.K & 7) == 0 && (p.ldo & 7) == 0;
+        const bool wide_out = wide && p.out_dtype == SF_BF16;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
+            // mask operand of this pixel tile, all loads first
+            uint2 axr[MT][4];
+            if (p.aux_mode && wide) {
+                uint4 ax4[MT][2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
+                        const bf16* src = (pv[c] && k < p.K) ? p.aux + pixoff[c] + k : zsrc;
+                        ax4[a][gp] = *reinterpret_cast<const uint4*>(src);
+                    }
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const uint4 d = ax4[a][gp];
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(d.x, d.z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(d.y, d.w, false, false);
+                        axr[a][2 * gp] = make_uint2(s0[0], s1[0]);
+                        axr[a][2 * gp + 1] = make_uint2(s0[1], s1[1]);
+                    }
+            } else if (p.aux_mode) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int k = it.k0 + a * 32 + 8 * g + 4 * h;
+                        const bf16* src = (pv[c] && k < p.K) ? p.aux + pixoff[c] + k : zsrc;
+                        axr[a][g] = *reinterpret_cast<const uint2*>(src);
+                    }
+            }
+            // bias / activation / mask for the four channels k .. k+3 this lane holds of group g
+            auto finish = [&](int a, int g, float* v) {
+                const int k = it.k0 + a * 32 + 8 * g + 4 * h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][c][4 * g + e];
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(sbias + (k < p.K ? k : 0));
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (p.act == SF_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                } else if (p.act == SF_ACT_LRELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                }
+                if (p.aux_mode) {
+                    const float neg = p.aux_mode == 1 ? 0.f : 0.2f;
+                    const unsigned u0 = axr[a][g].x, u1 = axr[a][g].y;
+                    // bf16 > 0  <=>  sign clear and not zero
+                    const bool p0 = !(u0 & 0x8000u) && (u0 & 0x7fffu), p1 = !(u0 & 0x80000000u) && (u0 & 0x7fff0000u);
+                    const bool p2 = !(u1 & 0x8000u) && (u1 & 0x7fffu), p3 = !(u1 & 0x80000000u) && (u1 & 0x7fff0000u);
+                    v[0] = p0 ? v[0] : neg * v[0]; v[1] = p1 ? v[1] : neg * v[1];
+                    v[2] = p2 ? v[2] : neg * v[2]; v[3] = p3 ? v[3] : neg * v[3];
+                }
+            };
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     float v0[4], v1[4];
-                    finish(c, a, 2 * gp, v0);
-                    finish(c, a, 2 * gp + 1, v1);
-                    if (wide) {
+                    finish(a, 2 * gp, v0);
+                    finish(a, 2 * gp + 1, v1);
+                    if (wide_out) {
                         const unsigned A0 = pack2(v0[0], v0[1]), A1 = pack2(v0[2], v0[3]);
                         const unsigned B0 = pack2(v1[0], v1[1]), B1 = pack2(v1[2], v1[3]);
                         const auto s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
@@ -538,6 +549,7 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
                         }
                     }
                 }
+        }
     };
 
     // ---- stage loop: cur = stage being computed, nxt = stage being copied
@@ -586,6 +598,11 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) {
     }
 }
 
+// (plain kernels around the templated body: hipcc does not emit the host stub of a kernel
+// template whose body holds these buffer-resource lambdas)
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) { conv3_dma_body<64, 32>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_wide_kernel(C3DParams p) { conv3_dma_body<128, 16>(p); }
+
 // tile of the persistent kernel: at most D_TP pixels, patch at most D_PP; fewest tiles, least halo
 void pick_tile_dma(int H, int W, int* th, int* tw) {
     long long best = -1;
@@ -602,7 +619,8 @@ void pick_tile_dma(int H, int W, int* th, int* tw) {
     *th = bth; *tw = btw;
 }
 
-int launch3_dma(const C3Params& q, hipStream_t s) {
+template <int KT, int CK> int launch3_dma(const C3Params& q, hipStream_t s) {
+    using Cf = DCfg<KT, CK>;
     C3DParams p;
     p.in = q.in; p.w = q.w; p.bias = q.bias; p.aux = q.aux; p.out = q.out;
     p.N = q.N; p.H = q.H; p.W = q.W; p.C = q.C; p.K = q.K; p.ldo = q.ldo;
@@ -618,12 +636,12 @@ int launch3_dma(const C3Params& q, hipStream_t s) {
         return SF_EINVAL;
     }
     p.ntiles = (int)ntiles;
-    p.ktiles = (p.K + D_KT - 1) / D_KT;
-    p.nchunks = (p.C + 31) / 32;
-    const size_t lds = 2 * (size_t)D_BUF + sizeof(float) * D_BIAS_MAX;
+    p.ktiles = (p.K + KT - 1) / KT;
+    p.nchunks = (p.C + CK - 1) / CK;
+    const size_t lds = 2 * (size_t)Cf::BUF + sizeof(float) * D_BIAS_MAX;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_dma_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(KT == 64 ? &conv3_dma_kernel : &conv3_dma_wide_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("sf_conv3x3: cannot raise the dynamic LDS limit to %zu bytes", lds);
             return SF_ELAUNCH;
@@ -633,7 +651,8 @@ int launch3_dma(const C3Params& q, hipStream_t s) {
     long long items = ntiles * p.ktiles;
     long long grid = (items + 7) / 8 * 8;
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(conv3_dma_kernel, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
+    if (KT == 64) hipLaunchKernelGGL(conv3_dma_kernel, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
+    else hipLaunchKernelGGL(conv3_dma_wide_kernel, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
     SF_LAUNCH_CHECK("sf_conv3x3");
     return SF_OK;
 }
@@ -696,7 +715,8 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
     p.tiles_x = (W + p.TW - 1) / p.TW;
     p.tiles_y = (H + p.TH - 1) / p.TH;
     hipStream_t s = (hipStream_t)stream;
-    if ((C % 32 == 0 || C == 16) && K <= D_BIAS_MAX) return launch3_dma(p, s);
+    if (K <= D_BIAS_MAX && C % 16 == 0 && (K > 64 || C % 32 != 0)) return launch3_dma<128, 16>(p, s);
+    if (K <= D_BIAS_MAX && C % 32 == 0) return launch3_dma<64, 32>(p, s);
     if (K <= 64 && C % 32 == 0) {
         p.ktiles = (K + 63) / 64;
         return launch3<64, 32>(p, s);
