@@ -77,6 +77,16 @@ int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, const float* bi
             const void* aux, void* out, void* stream);
 
 /*
+ * n <= 4 independent sf_gemm problems in one launch (more workgroups in flight than four small
+ * launches): used for the four output-parity classes of the PatchGAN's stride-2 data gradients
+ * (transposed nn.Conv2d(k=4,s=2,p=1), src/model/gan.py:20-33).  d: array of n descriptors; A, B,
+ * out: arrays of n pointers; bias, aux: arrays of n pointers or NULL.  All problems: row-major
+ * operands, nsplit 1, one dtype, I on the same side of 64.
+ */
+int sf_gemm_batch(int n, const sf_gemm_desc* d, const void* const* A, const void* const* B,
+                  const float* const* bias, const void* const* aux, void* const* out, void* stream);
+
+/*
  * 3x3 stride-1 convolution, bf16 NHWC, forward or data gradient (nn.Conv2d(k=3,p=1) at
  * src/model/cnn_encoder.py:45-51 and src/model/decoder.py:148-150): the (TH+2)x(TW+2) halo
  * patch of each input-channel chunk is staged in LDS once and shared by all nine taps.

@@ -91,8 +91,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
 }
 
-template <typename T, bool A_KM, bool B_KM, int TI, int BK = Mma<T>::BK>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
+template <typename T, bool A_KM, bool B_KM, int TI, int BK>
+__device__ __forceinline__ void gemm_body(const KParams& p, const int block_id, const int nwg) {
     using M = Mma<T>;
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int LDA = A_KM ? (TI + M::PAD_KM) : (BK + M::PAD_RM);
@@ -118,8 +118,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
     const int wi = wave >> 1, wj = wave & 1;
 
     // block -> (i tile, j tile, split)
-    const int nwg = gridDim.x;
-    int lin = xcd_remap(blockIdx.x, nwg);
+    int lin = xcd_remap(block_id, nwg);
     const int it_i = lin % p.ni_tiles;
     lin /= p.ni_tiles;
     const int it_j = lin % p.nj_tiles;
@@ -396,6 +395,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
     }
 }
 
+template <typename T, bool A_KM, bool B_KM, int TI, int BK = Mma<T>::BK>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(KParams p) {
+    gemm_body<T, A_KM, B_KM, TI, BK>(p, blockIdx.x, gridDim.x);
+}
+
+// Up to four independent problems of one kernel shape in a single launch (the four parity
+// classes of a stride-2 data gradient): workgroups [first[c], first[c+1]) work on problem c.
+constexpr int MAX_BATCH = 4;
+struct KBatch {
+    KParams k[MAX_BATCH];
+    int first[MAX_BATCH + 1];
+    int n;
+};
+
+template <typename T, int TI>
+__global__ __launch_bounds__(NTHREADS) void gemm_batch_kernel(KBatch b) {
+    int c = 0;
+    while (c + 1 < b.n && (int)blockIdx.x >= b.first[c + 1]) ++c;
+    gemm_body<T, false, false, TI, Mma<T>::BK>(b.k[c], blockIdx.x - b.first[c], b.first[c + 1] - b.first[c]);
+}
+
 template <typename T, bool A_KM, bool B_KM, int TI, int BK>
 int launch_one(const KParams& q, hipStream_t s) {
     using M = Mma<T>;
@@ -449,8 +469,8 @@ template <typename T> int dispatch(const sf_gemm_desc* d, const KParams& p, hipS
 
 }  // namespace
 
-extern "C" int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, const float* bias,
-                       const void* aux, void* out, void* stream) {
+static int fill_kparams(const sf_gemm_desc* d, const void* A, const void* B, const float* bias, const void* aux,
+                        void* out, KParams& p) {
     SF_REQUIRE(d && A && B && out, "sf_gemm: null argument");
     SF_REQUIRE(d->dtype == SF_F32 || d->dtype == SF_BF16, "sf_gemm: bad dtype %d", d->dtype);
     const int epc = d->dtype == SF_BF16 ? 8 : 4;
@@ -492,7 +512,6 @@ extern "C" int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, cons
     if (d->out_mode == SF_OUT_IJ || d->out_mode == SF_OUT_OIHW) SF_REQUIRE(d->out_dtype == SF_F32 && d->act == 0 && d->aux_mode == 0 && bias == nullptr, "sf_gemm: IJ/OIHW output is plain f32");
     if (d->aux_mode) SF_REQUIRE(aux != nullptr, "sf_gemm: aux_mode without aux");
 
-    KParams p;
     p.A = A; p.B = B; p.out = out; p.bias = bias; p.aux = aux;
     p.I = d->I; p.J = d->J; p.R = d->R; p.lda = d->lda; p.ldb = d->ldb; p.ldo = d->ldo;
     p.niters = p.iters_per_split = p.nsplit = 0;   // set per kernel variant in launch_one
@@ -510,8 +529,53 @@ extern "C" int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, cons
     }
     // a requested split keeps its accumulate-into-out semantics even when it degenerates to one slice
     p.atomic = (d->nsplit > 1 || d->out_mode == SF_OUT_OIHW) ? 1 : 0;
+    return SF_OK;
+}
+
+extern "C" int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, const float* bias,
+                       const void* aux, void* out, void* stream) {
+    KParams p;
+    if (int rc = fill_kparams(d, A, B, bias, aux, out, p)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    if (d->dtype == SF_BF16) rc = dispatch<bf16>(d, p, s); else rc = dispatch<float>(d, p, s);
-    return rc;
+    if (d->dtype == SF_BF16) return dispatch<bf16>(d, p, s);
+    return dispatch<float>(d, p, s);
+}
+
+template <typename T, int TI> static int launch_batch(KBatch& b, hipStream_t s) {
+    using M = Mma<T>;
+    constexpr int BK = M::BK;
+    constexpr size_t lds = sizeof(T) * 2 * (TI * (BK + M::PAD_RM) + TJ * (BK + M::PAD_RM));
+    long long total = 0;
+    for (int c = 0; c < b.n; ++c) {
+        KParams& p = b.k[c];
+        p.niters = ceil_div(p.R, BK);
+        p.nsplit = 1;
+        p.iters_per_split = p.niters;
+        p.ni_tiles = ceil_div(p.I, TI);
+        p.nj_tiles = ceil_div(p.J, TJ);
+        b.first[c] = (int)total;
+        total += (long long)p.ni_tiles * p.nj_tiles;
+        if (total > 0x3fffffffLL) { sf_set_error("sf_gemm_batch: bad grid"); return SF_EINVAL; }
+    }
+    for (int c = b.n; c <= MAX_BATCH; ++c) b.first[c] = (int)total;
+    hipLaunchKernelGGL((gemm_batch_kernel<T, TI>), dim3((unsigned)total), dim3(NTHREADS), lds, s, b);
+    SF_LAUNCH_CHECK("sf_gemm_batch");
+    return SF_OK;
+}
+
+extern "C" int sf_gemm_batch(int n, const sf_gemm_desc* d, const void* const* A, const void* const* B,
+                             const float* const* bias, const void* const* aux, void* const* out, void* stream) {
+    SF_REQUIRE(n >= 1 && n <= MAX_BATCH && d && A && B && out, "sf_gemm_batch: 1..%d problems", MAX_BATCH);
+    KBatch b;
+    b.n = n;
+    for (int c = 0; c < n; ++c) {
+        SF_REQUIRE(!d[c].a_kmajor && !d[c].b_kmajor && d[c].nsplit == 1 && d[c].dtype == d[0].dtype &&
+                   (d[c].I <= 64) == (d[0].I <= 64), "sf_gemm_batch: problems must share dtype, row-major operands, tile class and have nsplit 1");
+        if (int rc = fill_kparams(&d[c], A[c], B[c], bias ? bias[c] : nullptr, aux ? aux[c] : nullptr, out[c], b.k[c])) return rc;
+    }
+    for (int c = n; c < MAX_BATCH; ++c) b.k[c] = b.k[0];
+    hipStream_t s = (hipStream_t)stream;
+    const bool small = d[0].I <= 64;
+    if (d[0].dtype == SF_BF16) return small ? launch_batch<bf16, 64>(b, s) : launch_batch<bf16, 128>(b, s);
+    return small ? launch_batch<float, 64>(b, s) : launch_batch<float, 128>(b, s);
 }

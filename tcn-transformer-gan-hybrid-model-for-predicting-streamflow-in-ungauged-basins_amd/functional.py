@@ -387,13 +387,13 @@ class DiscriminatorFn(torch.autograd.Function):
             grads[2 + 6 * i + 2], grads[2 + 6 * i + 3] = dgamma, dbeta
             # data gradient: four parity classes of the transposed stride-2 conv
             dyin = torch.empty_like(yin)
+            problems = []
             for (py, px, taps, rs, mh, mw) in _s2_dgrad_classes(ih, iw):
                 wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, rs, True, C, K)
                 geom = ops.conv_geom(N, oh, ow, K, mh, mw, 1, 1, ih, iw, taps, osh=2, osw=2, ooy=py, oox=px)
-                if i == 0:  # layer below has no BatchNorm: fold its LeakyReLU derivative in
-                    ops.conv_fprop(dz, wT, dyin, geom, C, aux=yin, aux_mode=2)
-                else:
-                    ops.conv_fprop(dz, wT, dyin, geom, C)
+                # layer 0 sits on a conv without BatchNorm: fold its LeakyReLU derivative in
+                problems.append((dz, wT, dyin, geom, C, yin if i == 0 else None, 2 if i == 0 else 0))
+            ops.conv_fprop_batch(problems)   # the four parity classes in one launch
             dy = dyin
         dw1, db1 = ops.dconv1_bwd_weight(x, dy)
         grads[0], grads[1] = dw1, db1

@@ -61,7 +61,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_conv3x3", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
@@ -184,6 +184,27 @@ def conv_fprop(x, wp, out, geom: ConvGeom, K: int, bias=None, act=ACT_NONE, aux=
     d.nsplit, d.out_mode, d.out_dtype, d.act, d.aux_mode = 1, OUT_NHWC, code_of(out.dtype), act, aux_mode
     d.g = geom
     gemm(d, wp, x, out, bias, aux, tag)
+
+
+def conv_fprop_batch(problems):
+    """Up to four conv_fprop calls (x, wp, out, geom, K, aux, aux_mode) in one launch."""
+    n = len(problems)
+    descs = (GemmDesc * n)()
+    A, B, O, X = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+    any_aux = False
+    for i, (x, wp, out, geom, K, aux, aux_mode) in enumerate(problems):
+        _dev(x, wp, out, aux)
+        d = descs[i]
+        d.dtype = code_of(x.dtype)
+        d.a_kmajor, d.b_kmajor, d.b_gather = 0, 0, 1
+        d.I, d.J, d.R = K, geom.N * geom.MH * geom.MW, geom.ntaps * geom.C
+        d.lda, d.ldb, d.ldo = geom.ntaps * geom.C, geom.C, out.shape[-1]
+        d.nsplit, d.out_mode, d.out_dtype, d.act, d.aux_mode = 1, OUT_NHWC, code_of(out.dtype), ACT_NONE, aux_mode
+        d.g = geom
+        A[i], B[i], O[i] = wp.data_ptr(), x.data_ptr(), out.data_ptr()
+        X[i] = aux.data_ptr() if aux is not None else None
+        any_aux = any_aux or aux is not None
+    _check(lib().sf_gemm_batch(n, descs, A, B, None, X if any_aux else None, O, _stream()), "sf_gemm_batch")
 
 
 def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0, tag=None):
