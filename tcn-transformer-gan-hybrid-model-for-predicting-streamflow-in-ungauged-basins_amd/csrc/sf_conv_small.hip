@@ -232,6 +232,236 @@ __global__ __launch_bounds__(NT) void dconv1_bwd_weight_kernel(const float* __re
     });
 }
 
+// ---- MFMA forms of the first layer for bf16 tensors with K == 64 (the 16 taps are exactly the
+// reduction depth of one 32x32x16 MFMA; x is rounded to bf16 like a conv under autocast).
+__device__ __forceinline__ bf16x8 to_bf16x8(const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    return v;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 t;
+    t[0] = (bf16)a; t[1] = (bf16)b;
+    return *reinterpret_cast<const unsigned*>(&t);
+}
+
+// D[channel][pixel] = W[channel][tap] * patch[tap][pixel]: a wave owns the weights (two fragments)
+// and the bias for the whole kernel and walks 32-pixel groups; lane (p, h) gathers filter rows
+// 2h, 2h+1 of pixel p (8 clamped, masked loads) and ends up with channels 8g+4h+e of that pixel,
+// which one permlane32 swap per dword pair regroups into 16-byte stores.
+__global__ __launch_bounds__(NT) void dconv1_fwd_mfma_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ b, bf16* __restrict__ y,
+                                                             unsigned M, int H, int W, int OH, int OW) {
+    constexpr int U = 2;
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const unsigned wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (NT / 64);
+    bf16x8 wa[2];
+    float bias[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = w[(a * 32 + p) * 16 + 8 * h + j];
+        wa[a] = to_bf16x8(f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bias[a][i] = b[a * 32 + 8 * (i >> 2) + 4 * h + (i & 3)];
+    }
+    const unsigned ngroups = (M + 31) >> 5;
+    for (unsigned g = wave * U; g < ngroups; g += nwaves * U) {
+        float xv[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            unsigned m = (g + u) * 32 + p;
+            m = m < M ? m : M - 1;
+            const unsigned q = m / (unsigned)OW, ow = m - q * OW;
+            const unsigned n = q / (unsigned)OH, oh = q - n * OH;
+            const float* xin = x + (size_t)n * H * W;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int iy = (int)oh * 2 - 1 + 2 * h + (j >> 2), ix = (int)ow * 2 - 1 + (j & 3);
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                const float v = xin[cy * W + cx];
+                xv[u][j] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bf16x8 fb = to_bf16x8(xv[u]);
+            const unsigned m = (g + u) * 32 + p;
+            const bool live = m < M;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = bias[a][i];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[a], fb, acc, 0, 0, 0);
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = acc[8 * gp + e];
+                        v[e] = t > 0.f ? t : 0.2f * t;
+                    }
+                    const unsigned A0 = pack_bf16x2(v[0], v[1]), A1 = pack_bf16x2(v[2], v[3]);
+                    const unsigned B0 = pack_bf16x2(v[4], v[5]), B1 = pack_bf16x2(v[6], v[7]);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
+                    if (live)
+                        *reinterpret_cast<uint4*>(y + (size_t)m * 64 + a * 32 + 8 * (2 * gp + h)) =
+                            make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        }
+    }
+}
+
+// [dw | db][tap or bias row][channel] = A[row][pixel] * dz[pixel][channel] with the pixels as the
+// reduction: rows 0..15 of A are the taps of the pixel's patch, row 16 is all ones (bias
+// gradient), the rest zero.  Lane (r, h) covers the run of 8 pixels 8h..8h+7 of a 16-pixel group
+// (OW % 8 == 0 keeps a run inside one output row): 8 x loads for tap r, and 8 dword loads of
+// channels (2r, 2r+1) whose low / high halves feed two MFMAs (columns = even / odd channels).
+__global__ __launch_bounds__(NT) void dconv1_bwd_weight_mfma_kernel(const float* __restrict__ x,
+                                                                    const bf16* __restrict__ dz,
+                                                                    float* __restrict__ dw, float* __restrict__ db,
+                                                                    unsigned M, int H, int W, int OH, int OW) {
+    constexpr int U = 2;
+    __shared__ float sm[NT / 64][17][64];
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const unsigned wave = blockIdx.x * (NT / 64) + wv, nwaves = gridDim.x * (NT / 64);
+    const int t = r & 15, ty = t >> 2, tx = t & 3;
+    const unsigned nruns = M >> 3, ngroups = (nruns + 1) >> 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    for (unsigned g = wave * U; g < ngroups; g += nwaves * U) {
+        float xv[U][8];
+        unsigned d[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned run = (g + u) * 2 + h;
+            const bool live = run < nruns;
+            const unsigned m0 = live ? run * 8 : 0;
+            const unsigned q = m0 / (unsigned)OW, ow0 = m0 - q * OW;
+            const unsigned n = q / (unsigned)OH, oh = q - n * OH;
+            const int iy = (int)oh * 2 - 1 + ty;
+            const bool rok = iy >= 0 && iy < H;
+            const float* xrow = x + ((size_t)n * H + min(max(iy, 0), H - 1)) * W;
+            const bf16* dzp = dz + (size_t)m0 * 64 + 2 * r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ix = ((int)ow0 + j) * 2 - 1 + tx;
+                const float v = xrow[min(max(ix, 0), W - 1)];
+                xv[u][j] = (rok && ix >= 0 && ix < W) ? v : 0.f;
+                const unsigned dd = *reinterpret_cast<const unsigned*>(dzp + j * 64);
+                d[u][j] = live ? dd : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float av[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = r < 16 ? xv[u][j] : (r == 16 ? 1.f : 0.f);
+            const bf16x8 fa = to_bf16x8(av);
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo[i] = (d[u][2 * i] & 0xffffu) | (d[u][2 * i + 1] << 16);
+                hi[i] = (d[u][2 * i] >> 16) | (d[u][2 * i + 1] & 0xffff0000u);
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(lo), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(hi), acc[1], 0, 0, 0);
+        }
+    }
+    // acc[a][i]: row 8*(i>>2) + 4h + (i&3), channel 2r + a
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 8 * (i >> 2) + 4 * h + (i & 3);
+            if (row < 17) sm[wv][row][2 * r + a] = acc[a][i];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 17 * 64; i += NT) {
+        const int row = i >> 6, ch = i & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) s += sm[k][row][ch];
+        unsafeAtomicAdd(row < 16 ? dw + ch * 16 + row : db + ch, s);
+    }
+}
+
+// C[tap][pixel] = W^T[tap][channel] * dz[pixel][channel] with two 16x16x32 MFMAs (lane (col, q)
+// ends up with the four taps of filter row q of output pixel col), then col2im in registers:
+// input column 2ow-1 / 2ow sums taps tx = 0 / 1 of pixel ow and tx = 2 / 3 of pixel ow-1 (lane
+// col-1 of the same 16-lane row), and input row 2oh-1 / 2oh sums filter rows 0 / 1 of output row
+// oh and 2 / 3 of row oh-1 (lanes +32 of the previous iteration).  A wave marches down RB output
+// rows of a 16-column strip (15 new columns, one of overlap; one row of overlap on top); output
+// rows / columns OH / OW are virtual (zero dz) and close the last input row / column.
+__global__ __launch_bounds__(NT) void dconv1_bwd_data_mfma_kernel(const bf16* __restrict__ dz,
+                                                                  const float* __restrict__ w,
+                                                                  float* __restrict__ dx, int N, int H, int W, int OH,
+                                                                  int OW, int nstrips, int nchunks, int RB) {
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (NT / 64) + (threadIdx.x >> 6));
+    if (wave >= (unsigned)N * nstrips * nchunks) return;
+    const int strip = wave % nstrips;
+    const unsigned rest = wave / nstrips;
+    const int chunk = rest % nchunks, n = rest / nchunks;
+    bf16x8 wa[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = w[(32 * s + 8 * q + j) * 16 + col];
+        wa[s] = to_bf16x8(f);
+    }
+    const int ow = strip * 15 - 1 + col;
+    const bool cok = ow >= 0 && ow < OW;
+    const int ra = chunk * RB, rb = min(ra + RB, OH + 1);
+    const bf16* base = dz + ((size_t)n * OH * OW + min(max(ow, 0), OW - 1)) * 64 + 8 * q;
+    float prev0 = 0.f, prev1 = 0.f;
+    for (int oh0 = ra - 1; oh0 < rb; oh0 += U) {
+        uint4 d[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int oh = oh0 + u;
+            const bool ok = cok && oh >= 0 && oh < OH;
+            const bf16* p = base + (size_t)min(max(oh, 0), OH - 1) * OW * 64;
+            const uint4 v0 = *reinterpret_cast<const uint4*>(p), v1 = *reinterpret_cast<const uint4*>(p + 32);
+            d[u][0] = ok ? v0 : make_uint4(0, 0, 0, 0);
+            d[u][1] = ok ? v1 : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int oh = oh0 + u;
+            if (oh >= rb) break;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], *reinterpret_cast<const bf16x8*>(&d[u][0]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], *reinterpret_cast<const bf16x8*>(&d[u][1]), c, 0, 0, 0);
+            const float h0 = c[0] + __shfl_up(c[2], 1, 16), h1 = c[1] + __shfl_up(c[3], 1, 16);
+            const unsigned p0 = __float_as_uint(prev0), p1 = __float_as_uint(prev1);
+            const float pv0 = __uint_as_float(__builtin_amdgcn_permlane32_swap(p0, p0, false, false)[1]);
+            const float pv1 = __uint_as_float(__builtin_amdgcn_permlane32_swap(p1, p1, false, false)[1]);
+            const int iy = 2 * oh - 1 + q, ix = 2 * ow - 1;
+            if (oh >= ra && col >= 1 && q < 2 && iy >= 0 && iy < H) {
+                float* o = dx + ((size_t)n * H + iy) * W;
+                if (ix >= 0 && ix < W) o[ix] = h0 + pv0;
+                if (ix + 1 < W) o[ix + 1] = h1 + pv1;
+            }
+            prev0 = h0;
+            prev1 = h1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ single-output-channel conv
 // a group of LPP lanes handles one output pixel; lanes run over channel chunks.
 template <typename T>
@@ -694,6 +924,15 @@ extern "C" int sf_dconv1_fwd(const float* x, const float* w, const float* b, voi
     if (int rc = dconv1_dims("sf_dconv1_fwd", dtype, N, H, W, K, &OH, &OW)) return rc;
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const long long total = (long long)N * OH * OW * (K / epc);
+    if (dtype == SF_BF16 && K == 64 && (long long)N * OH * OW < 0x7fffffffLL) {
+        const long long M = (long long)N * OH * OW;
+        long long grid = (M + 32 * 2 * (NT / 64) - 1) / (32 * 2 * (NT / 64));
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(dconv1_fwd_mfma_kernel, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)stream, x, w, b,
+                           (bf16*)y, (unsigned)M, H, W, OH, OW);
+        SF_LAUNCH_CHECK("sf_dconv1_fwd");
+        return SF_OK;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_fwd_kernel<T>, dim3(grid_for(total)), dim3(NT), sizeof(float) * 17 * K,
                                          (hipStream_t)stream, x, w, b, (T*)y, N, H, W, K, OH, OW));
     SF_LAUNCH_CHECK("sf_dconv1_fwd");
@@ -708,6 +947,15 @@ extern "C" int sf_dconv1_bwd_data(const void* dz, int dtype, const float* w, flo
     const int epc_ = dtype == SF_BF16 ? 8 : 4;
     SF_REQUIRE(((K / epc_) & (K / epc_ - 1)) == 0 && K / epc_ <= 64, "sf_dconv1_bwd_data: K/chunk must be a power of two <= 64");
     const long long total = (long long)N * H * W * (K / epc_);
+    if (dtype == SF_BF16 && K == 64) {
+        const int RB = 25, nstrips = (OW + 1 + 14) / 15, nchunks = (OH + 1 + RB - 1) / RB;
+        const long long waves = (long long)N * nstrips * nchunks;
+        SF_REQUIRE(waves < 0x7fffffffLL, "sf_dconv1_bwd_data: too many strips");
+        hipLaunchKernelGGL(dconv1_bwd_data_mfma_kernel, dim3((unsigned)((waves + NT / 64 - 1) / (NT / 64))), dim3(NT), 0,
+                           (hipStream_t)stream, (const bf16*)dz, w, dx, N, H, W, OH, OW, nstrips, nchunks, RB);
+        SF_LAUNCH_CHECK("sf_dconv1_bwd_data");
+        return SF_OK;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(dconv1_bwd_data_kernel<T>, dim3(grid_for(total)), dim3(NT),
                                          sizeof(float) * 16 * K, (hipStream_t)stream, (const T*)dz, w, dx, N, H, W, K,
                                          OH, OW));
@@ -730,6 +978,15 @@ extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, f
     const int rpp = NT / (2 * (K / epc));
     const long long M = (long long)N * OH * OW;
     SF_REQUIRE(M < 0x7fffffffLL, "sf_dconv1_bwd_weight: too many pixels");
+    if (dtype == SF_BF16 && K == 64 && OW % 8 == 0) {
+        long long g = (M / 16 + 2 * (NT / 64) - 1) / (2 * (NT / 64));
+        if (g > 256) g = 256;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(dconv1_bwd_weight_mfma_kernel, dim3((unsigned)g), dim3(NT), 0, s, x, (const bf16*)dz, dw,
+                           db, (unsigned)M, H, W, OH, OW);
+        SF_LAUNCH_CHECK("sf_dconv1_bwd_weight");
+        return SF_OK;
+    }
     const int step = rpp * 4;
     long long grid = (M + step - 1) / step; if (grid > 256) grid = 256; if (grid < 1) grid = 1;
     long long per = ((M + grid - 1) / grid + step - 1) / step * step;

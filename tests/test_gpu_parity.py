@@ -524,3 +524,30 @@ def test_wgrad4x4s2_matches_reference(sf):
         ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2).cpu(), (K, C, 4, 4),
                                           dz.float().permute(0, 3, 1, 2).cpu(), stride=2, padding=1)
         close(dw, ref.numpy(), 1e-4)
+
+
+def test_dconv1_kernels_against_f32_conv(sf):
+    """First PatchGAN layer Conv2d(1,64,4,s2,p1)+LeakyReLU(0.2) (src/model/gan.py:37-41), bf16
+    tensors: forward, data gradient and weight / bias gradient against torch's f32 conv on
+    operands that are exactly representable in bf16 (the MFMA forms round x and w to bf16).
+    Even sizes (output width a multiple of 8), odd sizes and partial pixel groups.  Tolerances:
+    1e-2 of the max for the bf16 output, 1e-4 for the f32 gradients."""
+    ops = sf.ops
+    torch.manual_seed(5)
+    F = torch.nn.functional
+    for (N, H, W) in [(2, 64, 64), (3, 50, 50), (1, 33, 47), (2, 400, 400), (1, 2, 16)]:
+        K = 64
+        x = torch.randn(N, 1, H, W, device=DEV).to(torch.bfloat16).float()
+        w = (torch.randn(K, 1, 4, 4, device=DEV) * 0.25).to(torch.bfloat16).float()
+        b = torch.randn(K, device=DEV)
+        y = ops.dconv1_fwd(x, w, b, torch.bfloat16)
+        ref = F.leaky_relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), stride=2, padding=1), 0.2)
+        close(y.float().permute(0, 3, 1, 2), ref.numpy(), 1e-2)
+        OH, OW = y.shape[1], y.shape[2]
+        dz = torch.randn(N, OH, OW, K, device=DEV).to(torch.bfloat16)
+        dzc = dz.float().permute(0, 3, 1, 2).cpu()
+        dx = ops.dconv1_bwd_data(dz, w, H, W)
+        close(dx, torch.nn.grad.conv2d_input((N, 1, H, W), w.cpu(), dzc, stride=2, padding=1).numpy(), 1e-4)
+        dw, db = ops.dconv1_bwd_weight(x, dz)
+        close(dw, torch.nn.grad.conv2d_weight(x.cpu(), (K, 1, 4, 4), dzc, stride=2, padding=1).numpy(), 1e-4)
+        close(db, dzc.sum(dim=(0, 2, 3)).numpy(), 1e-4)
