@@ -325,14 +325,15 @@ __global__ __launch_bounds__(NT) void dconv1_fwd_mfma_kernel(const float* __rest
 // gradient), the rest zero.  Lane (r, h) covers the run of 8 pixels 8h..8h+7 of a 16-pixel group
 // (OW % 8 == 0 keeps a run inside one output row): 8 x loads for tap r, and 8 dword loads of
 // channels (2r, 2r+1) whose low / high halves feed two MFMAs (columns = even / odd channels).
-__global__ __launch_bounds__(NT) void dconv1_bwd_weight_mfma_kernel(const float* __restrict__ x,
+constexpr int WG_NT = 512;
+__global__ __launch_bounds__(WG_NT) void dconv1_bwd_weight_mfma_kernel(const float* __restrict__ x,
                                                                     const bf16* __restrict__ dz,
                                                                     float* __restrict__ dw, float* __restrict__ db,
                                                                     unsigned M, int H, int W, int OH, int OW) {
     constexpr int U = 2;
-    __shared__ float sm[NT / 64][17][64];
+    __shared__ float sm[WG_NT / 64][17][64];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    const unsigned wave = blockIdx.x * (NT / 64) + wv, nwaves = gridDim.x * (NT / 64);
+    const unsigned wave = blockIdx.x * (WG_NT / 64) + wv, nwaves = gridDim.x * (WG_NT / 64);
     const int t = r & 15, ty = t >> 2, tx = t & 3;
     const unsigned nruns = M >> 3, ngroups = (nruns + 1) >> 1;
     f32x16 acc[2];
@@ -343,6 +344,8 @@ __global__ __launch_bounds__(NT) void dconv1_bwd_weight_mfma_kernel(const float*
     for (unsigned g = wave * U; g < ngroups; g += nwaves * U) {
         float xv[U][8];
         unsigned d[U][8];
+        unsigned xok[U] = {};
+        bool lv[U];  // a dead run multiplies (valid, finite) dz of pixel 0 by a zero A column
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned run = (g + u) * 2 + h;
@@ -357,17 +360,26 @@ __global__ __launch_bounds__(NT) void dconv1_bwd_weight_mfma_kernel(const float*
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ix = ((int)ow0 + j) * 2 - 1 + tx;
-                const float v = xrow[min(max(ix, 0), W - 1)];
-                xv[u][j] = (rok && ix >= 0 && ix < W) ? v : 0.f;
-                const unsigned dd = *reinterpret_cast<const unsigned*>(dzp + j * 64);
-                d[u][j] = live ? dd : 0u;
+                xv[u][j] = xrow[min(max(ix, 0), W - 1)];
+                xok[u] |= (unsigned)(rok && ix >= 0 && ix < W) << j;
+                d[u][j] = *reinterpret_cast<const unsigned*>(dzp + j * 64);
             }
+            lv[u] = live;
         }
+        // the loaded values pass through an opaque statement before they are masked, so that the
+        // compiler cannot move a load under its mask's branch (which would serialise the loads)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                asm volatile("" : "+v"(xv[u][j]));
+                xv[u][j] = (xok[u] >> j & 1u) ? xv[u][j] : 0.f;
+            }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float av[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) av[j] = r < 16 ? xv[u][j] : (r == 16 ? 1.f : 0.f);
+            for (int j = 0; j < 8; ++j) av[j] = !lv[u] ? 0.f : (r < 16 ? xv[u][j] : (r == 16 ? 1.f : 0.f));
             const bf16x8 fa = to_bf16x8(av);
             unsigned lo[4], hi[4];
 #pragma unroll
@@ -388,11 +400,11 @@ __global__ __launch_bounds__(NT) void dconv1_bwd_weight_mfma_kernel(const float*
             if (row < 17) sm[wv][row][2 * r + a] = acc[a][i];
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < 17 * 64; i += NT) {
+    for (int i = threadIdx.x; i < 17 * 64; i += WG_NT) {
         const int row = i >> 6, ch = i & 63;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < NT / 64; ++k) s += sm[k][row][ch];
+        for (int k = 0; k < WG_NT / 64; ++k) s += sm[k][row][ch];
         unsafeAtomicAdd(row < 16 ? dw + ch * 16 + row : db + ch, s);
     }
 }
@@ -979,10 +991,10 @@ extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, f
     const long long M = (long long)N * OH * OW;
     SF_REQUIRE(M < 0x7fffffffLL, "sf_dconv1_bwd_weight: too many pixels");
     if (dtype == SF_BF16 && K == 64 && OW % 8 == 0) {
-        long long g = (M / 16 + 2 * (NT / 64) - 1) / (2 * (NT / 64));
+        long long g = (M / 16 + 2 * (WG_NT / 64) - 1) / (2 * (WG_NT / 64));
         if (g > 256) g = 256;
         if (g < 1) g = 1;
-        hipLaunchKernelGGL(dconv1_bwd_weight_mfma_kernel, dim3((unsigned)g), dim3(NT), 0, s, x, (const bf16*)dz, dw,
+        hipLaunchKernelGGL(dconv1_bwd_weight_mfma_kernel, dim3((unsigned)g), dim3(WG_NT), 0, s, x, (const bf16*)dz, dw,
                            db, (unsigned)M, H, W, OH, OW);
         SF_LAUNCH_CHECK("sf_dconv1_bwd_weight");
         return SF_OK;
