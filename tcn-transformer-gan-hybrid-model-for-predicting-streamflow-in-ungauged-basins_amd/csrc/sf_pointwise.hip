@@ -221,55 +221,110 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ src, T* __restrict
     }
 }
 
-// Upsampling by >= 7x along x: a thread produces a strip of 8 consecutive output pixels of one
-// row for one 8-channel group.  The strip touches at most 3 source columns, so the thread loads
-// 2 rows x 3 columns once (12 16-byte loads, issued together), interpolates vertically once per
-// column and horizontally per output.  32-bit indices.
+// Upsampling along x (OW >= w: the left source column of consecutive outputs advances by 0 or
+// 1): a thread walks a segment of one output row for one 16-byte channel group and keeps the
+// two source rows of the current column pair in registers (plus the next column, loaded one
+// advance ahead), so every output costs 6 flops per element and one store.  Same association
+// as the generic kernel.  Lanes of a wave share the segment, so the advance test is uniform.
 template <typename T>
-__global__ void bilinear_up_strip_kernel(const float* __restrict__ src, T* __restrict__ dst, unsigned total, int C,
-                                         int h, int w, int OH, int OW) {
-    constexpr int XS = 8;
-    const int G = C / 8;
-    const unsigned strips = (OW + XS - 1) / XS;
-    for (unsigned o = blockIdx.x * NT + threadIdx.x; o < total; o += gridDim.x * NT) {
-        const unsigned cg = o % G;
-        unsigned r = o / G;
-        const unsigned st = r % strips; r /= strips;
-        const unsigned oy = r % OH, b = r / OH;
-        const int ox0 = st * XS;
-        const AxisW ay = axis_w(oy, h, OH);
-        AxisW ax[XS];
+__global__ __launch_bounds__(NT) void bilinear_up_walk_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                              unsigned rows /* B*OH */, int C, int h, int w, int OH,
+                                                              int OW, int nseg) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const unsigned G = C / EPC;
+    const unsigned o = blockIdx.x * NT + threadIdx.x;
+    if (o >= rows * G * nseg) return;
+    const unsigned cg = o % G, r = (o / G) % rows, seg = o / (G * rows);
+    const unsigned oy = r % OH, b = r / OH;
+    const int x0 = (int)((long long)seg * OW / nseg), x1 = (int)((long long)(seg + 1) * OW / nseg);
+    const AxisW ay = axis_w(oy, h, OH);
+    const float* top = src + ((size_t)(b * h + ay.i0) * w) * C + cg * EPC;
+    const float* bot = src + ((size_t)(b * h + ay.i1) * w) * C + cg * EPC;
+    float a0[EPC], a1[EPC], b0[EPC], b1[EPC], c0[EPC], c1[EPC];
+    auto load_col = [&](int col, float* t, float* u) {
+        const int cc = col < w ? col : w - 1;
 #pragma unroll
-        for (int k = 0; k < XS; ++k) ax[k] = axis_w(ox0 + k < OW ? ox0 + k : OW - 1, w, OW);
-        const int c0 = ax[0].i0;
-        const float* base = src + ((size_t)b * h * w) * C + cg * 8;
-        float4 p[2][3][2];
+        for (int q = 0; q < EPC; q += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(top + (size_t)cc * C + q);
+            const float4 z = *reinterpret_cast<const float4*>(bot + (size_t)cc * C + q);
+            t[q] = v.x; t[q + 1] = v.y; t[q + 2] = v.z; t[q + 3] = v.w;
+            u[q] = z.x; u[q + 1] = z.y; u[q + 2] = z.z; u[q + 3] = z.w;
+        }
+    };
+    int cur = axis_w(x0, w, OW).i0;
+    load_col(cur, a0, a1);
+    load_col(cur + 1, b0, b1);
+    load_col(cur + 2, c0, c1);
+    T* out_row = dst + (size_t)r * OW * C + cg * EPC;
+    for (int ox = x0; ox < x1; ++ox) {
+        const AxisW ax = axis_w(ox, w, OW);
+        if (ax.i0 != cur) {
+            cur = ax.i0;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+            for (int e = 0; e < EPC; ++e) { a0[e] = b0[e]; a1[e] = b1[e]; b0[e] = c0[e]; b1[e] = c1[e]; }
+            load_col(cur + 2, c0, c1);
+        }
+        // ax.i1 is cur + 1, or cur at the right edge, where column cur + 1 is clamped to cur too
+        float out[EPC];
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                const int col = c0 + cc < w ? c0 + cc : w - 1;
-                const float* q = base + ((size_t)(rr ? ay.i1 : ay.i0) * w + col) * C;
-                p[rr][cc][0] = *reinterpret_cast<const float4*>(q);
-                p[rr][cc][1] = *reinterpret_cast<const float4*>(q + 4);
+        for (int e = 0; e < EPC; ++e)
+            out[e] = ay.l0 * (ax.l0 * a0[e] + ax.l1 * b0[e]) + ay.l1 * (ax.l0 * a1[e] + ax.l1 * b1[e]);
+        store_chunk<T>(out_row + (size_t)ox * C, out);
+    }
+}
+
+// Backward of the same along x (OW >= w): a thread walks one whole gradient row for one channel
+// group, reads every chunk once (batches of 8 unconditional loads) and adds it into the sums of
+// its left and right source columns; a column's sum is stored when the walk leaves it.
+template <typename T>
+__global__ __launch_bounds__(NT) void bilinear_bwd_x_walk_kernel(const T* __restrict__ ddst, float* __restrict__ tmp,
+                                                                 unsigned rows /* B*OH */, int C, int w, int OW) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int U = 8;
+    const unsigned G = C / EPC;
+    const unsigned o = blockIdx.x * NT + threadIdx.x;
+    if (o >= rows * G) return;
+    const unsigned cg = o % G, r = o / G;
+    const T* row = ddst + (size_t)r * OW * C + cg * EPC;
+    float* trow = tmp + (size_t)r * w * C + cg * EPC;
+    float acc0[EPC], acc1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc0[e] = acc1[e] = 0.f;
+    auto flush = [&](int col, const float* v) {
+#pragma unroll
+        for (int q = 0; q < EPC; q += 4)
+            *reinterpret_cast<float4*>(trow + (size_t)col * C + q) = make_float4(v[q], v[q + 1], v[q + 2], v[q + 3]);
+    };
+    int cur = 0;
+    for (int ox0 = 0; ox0 < OW; ox0 += U) {
+        float f[U][EPC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_chunk<T>(row + (size_t)(ox0 + u < OW ? ox0 + u : OW - 1) * C, f[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ox0 + u >= OW) break;
+            const AxisW a = axis_w(ox0 + u, w, OW);
+            if (a.i0 != cur) {
+                flush(cur, acc0);
+                cur = a.i0;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { acc0[e] = acc1[e]; acc1[e] = 0.f; }
             }
-        // keep the reference's association: ly0*(lx0*a00 + lx1*a01) + ly1*(lx0*a10 + lx1*a11)
+            if (a.i1 != a.i0) {
 #pragma unroll
-        for (int k = 0; k < XS; ++k) {
-            if (ox0 + k >= OW) break;
-            const int d0 = ax[k].i0 - c0, d1 = ax[k].i1 - c0;
-            float out[8];
+                for (int e = 0; e < EPC; ++e) { acc0[e] += a.l0 * f[u][e]; acc1[e] += a.l1 * f[u][e]; }
+            } else {
+                const float wv = a.l0 + a.l1;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a00 = d0 == 0 ? (&p[0][0][e >> 2].x)[e & 3] : d0 == 1 ? (&p[0][1][e >> 2].x)[e & 3] : (&p[0][2][e >> 2].x)[e & 3];
-                const float a01 = d1 == 0 ? (&p[0][0][e >> 2].x)[e & 3] : d1 == 1 ? (&p[0][1][e >> 2].x)[e & 3] : (&p[0][2][e >> 2].x)[e & 3];
-                const float a10 = d0 == 0 ? (&p[1][0][e >> 2].x)[e & 3] : d0 == 1 ? (&p[1][1][e >> 2].x)[e & 3] : (&p[1][2][e >> 2].x)[e & 3];
-                const float a11 = d1 == 0 ? (&p[1][0][e >> 2].x)[e & 3] : d1 == 1 ? (&p[1][1][e >> 2].x)[e & 3] : (&p[1][2][e >> 2].x)[e & 3];
-                out[e] = ay.l0 * (ax[k].l0 * a00 + ax[k].l1 * a01) + ay.l1 * (ax[k].l0 * a10 + ax[k].l1 * a11);
+                for (int e = 0; e < EPC; ++e) acc0[e] += wv * f[u][e];
             }
-            store_chunk<T>(dst + (((size_t)b * OH + oy) * OW + ox0 + k) * C + cg * 8, out);
         }
     }
+    flush(cur, acc0);
+    if (cur + 1 < w) flush(cur + 1, acc1);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc1[e] = 0.f;
+    for (int col = cur + 2; col < w; ++col) flush(col, acc1);
 }
 
 // pass 1: tmp[b][oy][sx][c] = sum_ox wx(ox -> sx) * ddst[b][oy][ox][c]
@@ -444,10 +499,17 @@ extern "C" int sf_bilinear_fwd(const void* src, int src_dtype, void* dst, int dt
     SF_REQUIRE(src_dtype == SF_F32, "sf_bilinear_fwd: source must be NHWC f32");
     SF_REQUIRE(C == Cpad && Cpad % (dtype == SF_BF16 ? 8 : 4) == 0, "sf_bilinear_fwd: C=%d must equal Cpad and be a chunk multiple", C);
     const int epc = dtype == SF_BF16 ? 8 : 4;
-    if (dtype == SF_BF16 && OW >= 7 * w && (long long)B * OH * ((OW + 7) / 8) * (C / 8) < 0x7fffffffLL) {
-        const long long items = (long long)B * OH * ((OW + 7) / 8) * (C / 8);
-        hipLaunchKernelGGL(bilinear_up_strip_kernel<bf16>, dim3(grid_for(items, 16384)), dim3(NT), 0, (hipStream_t)stream,
-                           (const float*)src, (bf16*)dst, (unsigned)items, C, h, w, OH, OW);
+    if (OW >= w && OW >= 16 && (long long)B * OH * (C / epc) * 64 < 0x7fffffffLL) {
+        // enough threads to fill the chip, segments of at least 16 outputs
+        const long long per_seg = (long long)B * OH * (C / epc);
+        long long nseg = (400000 + per_seg - 1) / per_seg;
+        if (nseg > OW / 16) nseg = OW / 16;
+        if (nseg > 64) nseg = 64;
+        if (nseg < 1) nseg = 1;
+        const long long items = per_seg * nseg;
+        DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_up_walk_kernel<T>, dim3((unsigned)((items + NT - 1) / NT)), dim3(NT),
+                                             0, (hipStream_t)stream, (const float*)src, (T*)dst, (unsigned)(B * OH), C,
+                                             h, w, OH, OW, (int)nseg));
         SF_LAUNCH_CHECK("sf_bilinear_fwd");
         return SF_OK;
     }
@@ -465,8 +527,14 @@ extern "C" int sf_bilinear_bwd(const void* ddst, int dtype, float* dsrc, float* 
     const int epc = dtype == SF_BF16 ? 8 : 4;
     hipStream_t s = (hipStream_t)stream;
     const long long t1 = (long long)B * OH * w * (C / epc);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_x_kernel<T>, dim3(grid_for(t1, 16384)), dim3(NT), 0, s,
-                                         (const T*)ddst, tmp, B, C, w, OH, OW));
+    if (OW >= w && (long long)B * OH * (C / epc) < 0x7fffffffLL) {
+        const long long items = (long long)B * OH * (C / epc);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_x_walk_kernel<T>, dim3((unsigned)((items + NT - 1) / NT)),
+                                             dim3(NT), 0, s, (const T*)ddst, tmp, (unsigned)(B * OH), C, w, OW));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_x_kernel<T>, dim3(grid_for(t1, 16384)), dim3(NT), 0, s,
+                                             (const T*)ddst, tmp, B, C, w, OH, OW));
+    }
     const long long t2 = (long long)B * h * w * (C / 4);
     hipLaunchKernelGGL(bilinear_bwd_y_kernel, dim3(grid_for(t2, 16384)), dim3(NT), 0, s, tmp, dsrc, B, C, h, w, OH);
     SF_LAUNCH_CHECK("sf_bilinear_bwd");
