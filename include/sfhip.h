@@ -181,6 +181,21 @@ int sf_bilinear_fwd(const void* src, int src_dtype, void* dst, int dtype, int B,
 int sf_bilinear_bwd(const void* ddst, int dtype, float* dsrc, float* tmp, int B, int C, int h,
                     int w, int OH, int OW, int Cpad, void* stream);
 
+/* ---- 3x3 conv of a bilinearly resized map, resized map never materialised ------------
+ * (src/model/decoder.py:165-173: F.interpolate(x, (OH,OW), mode='bilinear',
+ * align_corners=False) followed by Conv2d(C,K,3,padding=1) [+ReLU]).  The channel mixing is
+ * done first, on the source pixels, by the caller (a GEMM):
+ *   y9 f32 [B,h,w,9,K], y9[b][s][t][k] = sum_c W[k][c][t] x[b][s][c]   (t = 3*r + s of the filter)
+ * sf_upconv3_fwd: out[b][p][k] = act(bias[k] + sum_t resize(y9[..][t][..])[p + tap_t][k]), zero
+ * outside the resized image; out NHWC dtype [B,OH,OW,K]; act SF_ACT_NONE or SF_ACT_RELU.
+ * sf_upconv3_bwd: the adjoint, g[b][s][t][k] = sum_p lambda(p + tap_t -> s) dz[b][p][k]
+ * (g NHWC g_dtype [B,h,w,9,K]; dz NHWC dtype [B,OH,OW,K]; tmp: B*OH*3*w*K floats).  From g the
+ * caller gets dW = g^T x, dx = g W and db = column sums of g's centre tap with GEMMs. */
+int sf_upconv3_fwd(const float* y9, const float* bias, void* out, int dtype, int B, int h, int w,
+                   int OH, int OW, int K, int act, void* stream);
+int sf_upconv3_bwd(const void* dz, int dtype, float* tmp, void* g, int g_dtype, int B, int h,
+                   int w, int OH, int OW, int K, void* stream);
+
 /* ---- small convolutions that do not map onto MFMA tiles ---------------------------- */
 /* First PatchGAN layer: Conv2d(1,K,4,s2,p1)+bias+LeakyReLU (src/model/gan.py:37-41).
  * x f32 [N,1,H,W]; w f32 [K,1,4,4]; y NHWC dtype [N,OH,OW,K]. */

@@ -102,4 +102,20 @@ __device__ __forceinline__ double block_sum_256_d(double v, double* sm) {
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// bilinear source index / weights of one axis
+struct AxisW { int i0, i1; float l0, l1; };
+__device__ __forceinline__ AxisW axis_w(int dst, int in, int out) {
+    // ATen area_pixel_compute_source_index, align_corners=False, float arithmetic
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    AxisW a;
+    a.i0 = (int)src;
+    if (a.i0 > in - 1) a.i0 = in - 1;
+    a.i1 = a.i0 + (a.i0 < in - 1 ? 1 : 0);
+    a.l1 = src - (float)a.i0;
+    a.l0 = 1.f - a.l1;
+    return a;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

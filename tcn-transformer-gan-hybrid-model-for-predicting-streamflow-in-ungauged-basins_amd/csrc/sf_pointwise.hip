@@ -175,21 +175,6 @@ __global__ void bn_relu_avgpool_fwd_kernel(const T* __restrict__ x, const float*
 }
 
 // ------------------------------------------------------------------------------ bilinear
-struct AxisW { int i0, i1; float l0, l1; };
-__device__ __forceinline__ AxisW axis_w(int dst, int in, int out) {
-    // ATen area_pixel_compute_source_index, align_corners=False, float arithmetic
-    const float scale = (float)in / (float)out;
-    float src = scale * ((float)dst + 0.5f) - 0.5f;
-    if (src < 0.f) src = 0.f;
-    AxisW a;
-    a.i0 = (int)src;
-    if (a.i0 > in - 1) a.i0 = in - 1;
-    a.i1 = a.i0 + (a.i0 < in - 1 ? 1 : 0);
-    a.l1 = src - (float)a.i0;
-    a.l0 = 1.f - a.l1;
-    return a;
-}
-
 // src NHWC f32 [B,h,w,C] -> dst NHWC T [B,OH,OW,C]
 template <typename T>
 __global__ void bilinear_fwd_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int h,

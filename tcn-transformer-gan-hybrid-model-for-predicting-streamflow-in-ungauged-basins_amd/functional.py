@@ -231,8 +231,19 @@ class LstmFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------ decoder
+def _pix_geom(B, h, w, C):
+    """Geometry of a per-pixel (1x1) GEMM over an NHWC map."""
+    return ops.conv_geom(B, h, w, C, h, w, 1, 1, h, w, [(0, 0)], tap_rs=[0])
+
+
 class DecoderFn(torch.autograd.Function):
-    """SimpleUpsamplingDecoder.forward (src/model/decoder.py:154-177)."""
+    """SimpleUpsamplingDecoder.forward (src/model/decoder.py:154-177).
+
+    The bilinear resize and conv1 are both linear and the resize only touches pixels, so conv1's
+    channel mixing is applied to the small source map first (a GEMM giving 9*K values per source
+    pixel, one K-vector per filter tap) and the 16x larger resized map is never built:
+    ops.upconv3_fwd sums, per output pixel, the interpolated tap maps; the backward goes through
+    the adjoint map g (ops.upconv3_bwd) and three small GEMMs."""
 
     @staticmethod
     def forward(ctx, x, OH, OW, cdtype, w1, b1, w2, b2, w3, b3):
@@ -241,26 +252,30 @@ class DecoderFn(torch.autograd.Function):
             raise NotImplementedError("decoder input channels must be a multiple of 8 on the HIP path")
         Hc = w1.shape[0]
         Hp = ops.roundup(Hc, 8)
-        src = ops.nchw_to_nhwc(x.contiguous().float(), torch.float32, C)
-        up = ops.bilinear_fwd(src, OH, OW, cdtype)
-        w1p = ops.pack_conv_weight(w1.detach().contiguous(), cdtype, list(range(9)), False, Hp, C)
-        w2p = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), False, Hp, Hp)
+        src = ops.nchw_to_nhwc(x.contiguous().float(), cdtype, C)
+        # rows (tap, k): w9[t * Hp + k][c] = w1[k][c][t]; padded output channels are zero rows
+        w9 = torch.zeros((9, Hp, C), device=x.device, dtype=torch.float32)
+        w9[:, :Hc] = w1.detach().reshape(Hc, C, 9).permute(2, 0, 1)
+        w9 = w9.view(9 * Hp, C, 1, 1)
+        w9p = ops.pack_conv_weight(w9, cdtype, [0], False, 9 * Hp, C)
+        y9 = torch.empty((B, h, w, 9 * Hp), device=x.device, dtype=torch.float32)
+        ops.conv_fprop(src, w9p, y9, _pix_geom(B, h, w, C), 9 * Hp)
         bp1 = _pad_vec(b1.detach(), Hp)
+        h1 = ops.upconv3_fwd(y9.view(B, h, w, 9, Hp), bp1, OH, OW, cdtype, relu=True)
+        w2p = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), False, Hp, Hp)
         bp2 = _pad_vec(b2.detach(), Hp)
-        h1 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
-        ops.conv3x3(up, w1p, h1, Hp, bias=bp1, act=ops.ACT_RELU, tag="dec_conv1_fprop")
         h2 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
         ops.conv3x3(h1, w2p, h2, Hp, bias=bp2, act=ops.ACT_RELU)
         w3c = w3.detach().contiguous()
         y = ops.conv_k1_fwd(h2, w3c, b3.detach().contiguous(), 1, 0)
-        ctx.save_for_backward(up, h1, h2, w3c)
+        ctx.save_for_backward(src, h1, h2, w3c, w9)
         ctx.weights = (w1, w2)
         ctx.dims = (B, C, h, w, OH, OW, Hc, Hp, cdtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        up, h1, h2, w3c = ctx.saved_tensors
+        src, h1, h2, w3c, w9 = ctx.saved_tensors
         w1, w2 = ctx.weights
         B, C, h, w, OH, OW, Hc, Hp, cdtype = ctx.dims
         dy = dy.contiguous().float()
@@ -272,15 +287,19 @@ class DecoderFn(torch.autograd.Function):
         w2T = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), True, Hp, Hp)
         dz1 = torch.empty_like(h1)
         ops.conv3x3(dz2, w2T, dz1, Hp, dgrad=True, aux=h1, aux_mode=1)
-        dw1 = torch.empty_like(w1)
-        ops.wgrad3x3(up, dz1, dw1, tag="dec_conv1_wgrad")
-        db1 = ops.channel_sum(dz1, Hc)
+        g = ops.upconv3_bwd(dz1, h, w, cdtype).view(B, h, w, 9 * Hp)
+        # dW9[(t,k)][c] = sum_pixels g[pixel][(t,k)] * src[pixel][c]
+        dw9 = torch.zeros((9 * Hp, C, 1, 1), device=dy.device, dtype=torch.float32)
+        ops.conv_wgrad(src, g, dw9, ops.conv_geom(B, h, w, C, h, w, 1, 1, h, w, [(0, 0)], tap_rs=[0], cin_real=C, RS=1),
+                       9 * Hp)
+        dw1 = dw9.view(9, Hp, C)[:, :Hc].permute(1, 2, 0).reshape(Hc, C, 3, 3)
+        # the interpolation weights of a pixel sum to one: the centre tap of g sums to sum_p dz1[p]
+        db1 = g.view(-1, 9, Hp)[:, 4, :Hc].float().sum(dim=0)
         dx = None
         if ctx.needs_input_grad[0]:
-            w1T = ops.pack_conv_weight(w1.detach().contiguous(), cdtype, list(range(9)), True, C, Hp)
-            dup = torch.empty_like(up)
-            ops.conv3x3(dz1, w1T, dup, C, dgrad=True, tag="dec_conv1_dgrad")
-            dsrc = ops.bilinear_bwd(dup, h, w)
+            w9T = ops.pack_conv_weight(w9, cdtype, [0], True, C, 9 * Hp)
+            dsrc = torch.empty((B, h, w, C), device=dy.device, dtype=torch.float32)
+            ops.conv_fprop(g, w9T, dsrc, _pix_geom(B, h, w, 9 * Hp), C)
             dx = ops.nhwc_to_nchw(dsrc, C)
         return dx, None, None, None, dw1, db1, dw2, db2, dw3, db3
 

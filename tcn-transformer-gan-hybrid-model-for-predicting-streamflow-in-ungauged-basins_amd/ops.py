@@ -64,7 +64,7 @@ def lib():
 EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
-           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
+           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
            "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
@@ -219,8 +219,10 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
     if x.dtype == torch.bfloat16 and C % 16 == 0 and not FORCE_GENERIC_CONV:
         _dev(x, wp, out, bias, aux)
         rec = TIMED.get(tag) if tag is not None else None
-        if rec is None and C % 32 == 0:
-            rec = TIMED.get("conv3_dma_kernel")   # every launch of the persistent kernel
+        if rec is None:
+            # every launch of the persistent kernel, by variant (same rule as sf_conv3x3's dispatch)
+            wide = K <= 1024 and (K > 64 or C % 32 != 0)
+            rec = TIMED.get("conv3_dma_wide_kernel" if wide else "conv3_dma_kernel") if (wide or C % 32 == 0) else None
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -438,6 +440,29 @@ def bilinear_bwd(ddst: torch.Tensor, h: int, w: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------ small convs
+def upconv3_fwd(y9: torch.Tensor, bias: Optional[torch.Tensor], OH: int, OW: int, dtype: torch.dtype,
+                relu: bool) -> torch.Tensor:
+    """act(bias + sum over the 9 taps of the resized, shifted tap maps); y9 f32 [B,h,w,9,K]."""
+    _dev(y9, bias, dtypes=[torch.float32, torch.float32])
+    B, h, w, nine, K = y9.shape
+    assert nine == 9
+    out = torch.empty((B, OH, OW, K), device=y9.device, dtype=dtype)
+    _check(lib().sf_upconv3_fwd(_p(y9), _p(bias), _p(out), code_of(dtype), B, h, w, OH, OW, K,
+                                ACT_RELU if relu else ACT_NONE, _stream()), "sf_upconv3_fwd")
+    return out
+
+
+def upconv3_bwd(dz: torch.Tensor, h: int, w: int, g_dtype: torch.dtype) -> torch.Tensor:
+    """Adjoint of upconv3_fwd's gather: dz NHWC [B,OH,OW,K] -> g [B,h,w,9,K]."""
+    _dev(dz)
+    B, OH, OW, K = dz.shape
+    tmp = torch.empty(B * OH * 3 * w * K, device=dz.device, dtype=torch.float32)
+    g = torch.empty((B, h, w, 9, K), device=dz.device, dtype=g_dtype)
+    _check(lib().sf_upconv3_bwd(_p(dz), code_of(dz.dtype), _p(tmp), _p(g), code_of(g_dtype), B, h, w, OH, OW, K,
+                                _stream()), "sf_upconv3_bwd")
+    return g
+
+
 def dconv1_fwd(x, w, b, dtype):
     _dev(x, w, b, dtypes=[torch.float32] * 3)
     N, _, H, W = x.shape
