@@ -124,45 +124,35 @@ __global__ __launch_bounds__(UT) void upconv3_fwd_kernel(const float* __restrict
 // a source index is final -- and handed to `emit(index, sums)` -- once the left index has moved
 // past it.  Source indices that receive nothing are emitted as zeros, so every index in
 // [0, n_in) is emitted exactly once, whatever the scale.
-template <int NV> struct AdjointCursor {
-    float s0[NV], s1[NV];
+template <int NV> struct AdjointCursor {  // sums kept as 4-wide vectors (NV / 4 of them per index)
+    static constexpr int NQ = NV / 4;
+    f32x4 s0[NQ], s1[NQ];
     int cur;
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int e = 0; e < NV; ++e) s0[e] = s1[e] = 0.f;
+        for (int q = 0; q < NQ; ++q) s0[q] = s1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         cur = -1;
     }
-    template <typename F> __device__ __forceinline__ void add(const AxisW& a, const float* f, F emit) {
-        if (a.i0 != cur) {
-            if (cur >= 0) emit(cur, s0);
-            if (a.i0 == cur + 1) {
+    // emit(cur) and slide the window one index to the right; emit ignores negative indices
+    template <typename F> __device__ __forceinline__ void shift(F emit) {
+        emit(cur, s0);
 #pragma unroll
-                for (int e = 0; e < NV; ++e) s0[e] = s1[e];
-            } else {
-                emit(cur + 1, s1);
-#pragma unroll
-                for (int e = 0; e < NV; ++e) s0[e] = 0.f;
-                for (int i = cur + 2; i < a.i0; ++i) emit(i, s0);
-            }
-#pragma unroll
-            for (int e = 0; e < NV; ++e) s1[e] = 0.f;
-            cur = a.i0;
-        }
+        for (int q = 0; q < NQ; ++q) { s0[q] = s1[q]; s1[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        ++cur;
+    }
+    template <typename F> __device__ __forceinline__ void add(const AxisW& a, const f32x4* f, F emit) {
+        while (cur != a.i0) shift(emit);  // one step per advance when upsampling
         if (a.i1 != a.i0) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) { s0[e] += a.l0 * f[e]; s1[e] += a.l1 * f[e]; }
+            for (int q = 0; q < NQ; ++q) { s0[q] += a.l0 * f[q]; s1[q] += a.l1 * f[q]; }
         } else {
             const float wv = a.l0 + a.l1;
 #pragma unroll
-            for (int e = 0; e < NV; ++e) s0[e] += wv * f[e];
+            for (int q = 0; q < NQ; ++q) s0[q] += wv * f[q];
         }
     }
     template <typename F> __device__ __forceinline__ void finish(int n_in, F emit) {
-        if (cur >= 0) emit(cur, s0);
-        if (cur + 1 < n_in) emit(cur + 1, s1);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) s0[e] = 0.f;
-        for (int i = cur + 2; i < n_in; ++i) emit(i, s0);
+        while (cur < n_in) shift(emit);
     }
 };
 
@@ -179,9 +169,17 @@ __global__ __launch_bounds__(UT) void upconv3_bwd_x_kernel(const T* __restrict__
     const unsigned cg = o % G8, r = o / G8;
     const T* row = dz + (size_t)r * OW * K + cg * 8;
     float* trow = tm + (size_t)r * 3 * w * K + cg * 8;
-    AdjointCursor<8> cs[3];
-#pragma unroll
-    for (int tx = 0; tx < 3; ++tx) cs[tx].init();
+    // six 4-channel cursors (3 column shifts x 2 halves): arrays of sums end up in scratch
+    AdjointCursor<4> c0a, c0b, c1a, c1b, c2a, c2b;
+    c0a.init(); c0b.init(); c1a.init(); c1b.init(); c2a.init(); c2b.init();
+    auto feed = [&](AdjointCursor<4>& c, int tx, int half, int ox, const f32x4& fv) __attribute__((always_inline)) {
+        const int qx = ox + tx - 1;
+        if (qx < 0 || qx >= OW) return;
+        float* dst = trow + (size_t)tx * w * K + half * 4;
+        c.add(axis_w(qx, w, OW), &fv, [&](int col, const f32x4* v) __attribute__((always_inline)) {
+            if (col >= 0) *reinterpret_cast<f32x4*>(dst + (size_t)col * K) = v[0];
+        });
+    };
     for (int ox0 = 0; ox0 < OW; ox0 += U) {
         float f[U][8];
 #pragma unroll
@@ -189,21 +187,21 @@ __global__ __launch_bounds__(UT) void upconv3_bwd_x_kernel(const T* __restrict__
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ox = ox0 + u;
-            if (ox >= OW) break;
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
-                const int qx = ox + tx - 1;
-                if (qx < 0 || qx >= OW) continue;
-                float* dst = trow + (size_t)tx * w * K;
-                cs[tx].add(axis_w(qx, w, OW), f[u], [&](int col, const float* v) { store8<float>(dst + (size_t)col * K, v); });
+            if (ox < OW) {
+                const f32x4 fa = {f[u][0], f[u][1], f[u][2], f[u][3]}, fb = {f[u][4], f[u][5], f[u][6], f[u][7]};
+                feed(c0a, 0, 0, ox, fa); feed(c0b, 0, 1, ox, fb);
+                feed(c1a, 1, 0, ox, fa); feed(c1b, 1, 1, ox, fb);
+                feed(c2a, 2, 0, ox, fa); feed(c2b, 2, 1, ox, fb);
             }
         }
     }
-#pragma unroll
-    for (int tx = 0; tx < 3; ++tx) {
-        float* dst = trow + (size_t)tx * w * K;
-        cs[tx].finish(w, [&](int col, const float* v) { store8<float>(dst + (size_t)col * K, v); });
-    }
+    auto done = [&](AdjointCursor<4>& c, int tx, int half) __attribute__((always_inline)) {
+        float* dst = trow + (size_t)tx * w * K + half * 4;
+        c.finish(w, [&](int col, const f32x4* v) __attribute__((always_inline)) {
+            if (col >= 0) *reinterpret_cast<f32x4*>(dst + (size_t)col * K) = v[0];
+        });
+    };
+    done(c0a, 0, 0); done(c0b, 0, 1); done(c1a, 1, 0); done(c1b, 1, 1); done(c2a, 2, 0); done(c2b, 2, 1);
 }
 
 // vertical pass: g[b][i][j][ty*3+tx][k] = sum_oy lambda_y(oy + ty - 1 -> i) tm[b][oy][tx][j][k].
@@ -212,7 +210,7 @@ __global__ __launch_bounds__(UT) void upconv3_bwd_x_kernel(const T* __restrict__
 template <typename TG>
 __global__ __launch_bounds__(UT) void upconv3_bwd_y_kernel(const float* __restrict__ tm, TG* __restrict__ g, int B,
                                                            int h, int w, int OH, int K, int nseg) {
-    constexpr int U = 4;
+    constexpr int U = 8;
     const unsigned K4 = K / 4, per_img = 3 * w * K4;
     const unsigned o = blockIdx.x * UT + threadIdx.x;
     if (o >= (unsigned)B * nseg * per_img) return;
@@ -230,18 +228,22 @@ __global__ __launch_bounds__(UT) void upconv3_bwd_y_kernel(const float* __restri
     const float* col = tm + (((size_t)b * OH * 3 + tx) * w + j) * K + k4 * 4;  // + oy * 3*w*K
     const size_t ostride = (size_t)3 * w * K;
     TG* gb = g + (((size_t)b * h * w + j) * 9 + tx) * K + k4 * 4;  // + i * w*9*K + ty * 3*K
-    AdjointCursor<4> cs[3];
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty) cs[ty].init();
-    auto emit_to = [&](int ty) {
-        return [=](int i, const float* v) {
+    AdjointCursor<4> c0, c1, c2;
+    c0.init(); c1.init(); c2.init();
+    auto emit_to = [&](int ty) __attribute__((always_inline)) {
+        return [=](int i, const f32x4* v) __attribute__((always_inline)) {
             if (i >= ia && i < ib) {
                 Vec4<TG> q;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q.set(e, v[e]);
+                for (int e = 0; e < 4; ++e) q.set(e, v[0][e]);
                 q.store(gb + (size_t)i * w * 9 * K + (size_t)ty * 3 * K);
             }
         };
+    };
+    auto feed = [&](AdjointCursor<4>& c, int ty, int oy, const f32x4* fv) __attribute__((always_inline)) {
+        const int qy = oy + ty - 1;
+        if (qy < 0 || qy >= OH) return;
+        c.add(axis_w(qy, h, OH), fv, emit_to(ty));
     };
     for (int oy0 = lo; oy0 <= hi; oy0 += U) {
         float4 f[U];
@@ -250,18 +252,17 @@ __global__ __launch_bounds__(UT) void upconv3_bwd_y_kernel(const float* __restri
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int oy = oy0 + u;
-            if (oy > hi) break;
-            const float fv[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
-#pragma unroll
-            for (int ty = 0; ty < 3; ++ty) {
-                const int qy = oy + ty - 1;
-                if (qy < 0 || qy >= OH) continue;
-                cs[ty].add(axis_w(qy, h, OH), fv, emit_to(ty));
+            if (oy <= hi) {
+                const f32x4 fv[1] = {f32x4{f[u].x, f[u].y, f[u].z, f[u].w}};
+                feed(c0, 0, oy, fv);
+                feed(c1, 1, oy, fv);
+                feed(c2, 2, oy, fv);
             }
         }
     }
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty) cs[ty].finish(h, emit_to(ty));
+    c0.finish(h, emit_to(0));
+    c1.finish(h, emit_to(1));
+    c2.finish(h, emit_to(2));
 }
 
 int check_dims(const char* who, int B, int h, int w, int OH, int OW, int K) {
