@@ -551,3 +551,57 @@ def test_dconv1_kernels_against_f32_conv(sf):
         dw, db = ops.dconv1_bwd_weight(x, dz)
         close(dw, torch.nn.grad.conv2d_weight(x.cpu(), (K, 1, 4, 4), dzc, stride=2, padding=1).numpy(), 1e-4)
         close(db, dzc.sum(dim=(0, 2, 3)).numpy(), 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upconv3_against_interpolate_then_conv(sf, dtype):
+    """sf_upconv3_fwd / sf_upconv3_bwd (3x3 conv of a bilinearly resized map, resized map never
+    built) against F.interpolate(bilinear, align_corners=False) + conv2d in f32 on the CPU
+    (src/model/decoder.py:165-173), forward and all three gradients, through DecoderFn's GEMMs.
+    Up- and down-sampling, odd sizes, non-square maps.  f32: 1e-5 of the max (forward), 1e-4
+    (gradients); bf16 operands: 2e-2."""
+    ops = sf.ops
+    F = torch.nn.functional
+    torch.manual_seed(11)
+    tol_f, tol_g = (1e-5, 1e-4) if dtype == torch.float32 else (2e-2, 2e-2)
+    for (B, C, h, w, OH, OW, K) in [(2, 16, 8, 8, 100, 100, 8), (1, 32, 5, 7, 33, 20, 16), (3, 8, 12, 9, 7, 30, 24),
+                                    (2, 64, 32, 32, 64, 64, 64)]:
+        x = torch.randn(B, C, h, w, device=DEV)
+        wt = torch.randn(K, C, 3, 3, device=DEV) / (3.0 * C ** 0.5)
+        bias = torch.randn(K, device=DEV)
+        if dtype == torch.bfloat16:
+            x, wt = x.to(dtype).float(), wt.to(dtype).float()
+        xr, wr = x.cpu().requires_grad_(), wt.cpu().requires_grad_()
+        up = F.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=False)
+        ref = torch.relu(F.conv2d(up, wr, bias.cpu(), padding=1))
+        dout = torch.randn(B, K, OH, OW)
+        ref.backward(dout)
+        # HIP path: per-source-pixel GEMM, then the resize-accumulate kernel
+        src = ops.nchw_to_nhwc(x, dtype, C)
+        w9 = wt.reshape(K, C, 9).permute(2, 0, 1).contiguous().view(9 * K, C, 1, 1)
+        geom = ops.conv_geom(B, h, w, C, h, w, 1, 1, h, w, [(0, 0)], tap_rs=[0])
+        y9 = torch.empty(B, h, w, 9 * K, device=DEV)
+        ops.conv_fprop(src, ops.pack_conv_weight(w9, dtype, [0], False, 9 * K, C), y9, geom, 9 * K)
+        out = ops.upconv3_fwd(y9.view(B, h, w, 9, K), bias, OH, OW, dtype, relu=True)
+        close(out.float().permute(0, 3, 1, 2), ref.detach().numpy(), tol_f)
+        dz = (dout.to(DEV) * (ref.detach().to(DEV) > 0)).permute(0, 2, 3, 1).contiguous().to(dtype)
+        g = ops.upconv3_bwd(dz, h, w, dtype).view(B, h, w, 9 * K)
+        dw9 = torch.zeros(9 * K, C, 1, 1, device=DEV)
+        ops.conv_wgrad(src, g, dw9, ops.conv_geom(B, h, w, C, h, w, 1, 1, h, w, [(0, 0)], tap_rs=[0], cin_real=C, RS=1),
+                       9 * K)
+        dw = dw9.view(9, K, C).permute(1, 2, 0).reshape(K, C, 3, 3)
+        dsrc = torch.empty(B, h, w, C, device=DEV)
+        ops.conv_fprop(g, ops.pack_conv_weight(w9, dtype, [0], True, C, 9 * K), dsrc,
+                       ops.conv_geom(B, h, w, 9 * K, h, w, 1, 1, h, w, [(0, 0)], tap_rs=[0]), C)
+        db = g.view(-1, 9, K)[:, 4].float().sum(0)
+        if dtype == torch.bfloat16:
+            # reference gradients from the same bf16-rounded dz
+            xr.grad = None; wr.grad = None
+            up = F.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=False)
+            F.conv2d(up, wr, None, padding=1).backward(dz.float().permute(0, 3, 1, 2).cpu())
+            dzsum = dz.float().sum(dim=(0, 1, 2)).cpu()
+        else:
+            dzsum = (dout * (ref.detach() > 0)).sum(dim=(0, 2, 3))
+        close(dw, wr.grad.numpy(), tol_g)
+        close(dsrc.permute(0, 3, 1, 2), xr.grad.numpy(), tol_g)
+        close(db, dzsum.numpy(), tol_g)
