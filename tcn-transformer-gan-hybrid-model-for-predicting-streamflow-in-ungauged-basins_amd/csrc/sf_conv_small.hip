@@ -888,6 +888,78 @@ __global__ __launch_bounds__(NT) void head_bwd_weight_kernel(const T* __restrict
     }
 }
 
+// MFMA form for bf16 and 4x4 filters: D[channel][tap] = sum over input pixels of
+// x[pixel][channel] * dy[pixel + pad - tap].  Lane (r, h) covers pixels 8h..8h+7 of a 16-pixel
+// group: 8 dword loads of channels (2r, 2r+1) whose low / high halves feed two MFMAs (rows =
+// even / odd channels of a 64-channel block), and 8 dy gathers for tap r (columns >= 16 unused).
+// A workgroup owns one 64-channel block and a pixel range; its 4 waves interleave the groups.
+__global__ __launch_bounds__(NT) void head_bwd_weight_mfma_kernel(const bf16* __restrict__ x,
+                                                                  const float* __restrict__ dy,
+                                                                  float* __restrict__ dw, float* __restrict__ db,
+                                                                  unsigned M, unsigned per, unsigned Mout, int H, int W,
+                                                                  int C, int Creal, int pad, int OH, int OW,
+                                                                  int nsplit) {
+    __shared__ float sm[NT / 64][16][64];
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int cb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const unsigned m_lo = sp * per, m_hi = m_lo + per < M ? m_lo + per : M;
+    const int ty = (r & 15) >> 2, tx = r & 3;
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    const bf16* xb = x + cb * 64 + 2 * r;
+    for (unsigned g0 = m_lo + wv * 16; g0 < m_hi; g0 += (NT / 64) * 16) {
+        unsigned d[8];
+        float gy[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned m = g0 + 8 * h + j;
+            const bool live = m < m_hi;
+            const unsigned mc = live ? m : m_lo;
+            d[j] = *reinterpret_cast<const unsigned*>(xb + (size_t)mc * C);
+            const unsigned q = mc / (unsigned)W, ix = mc - q * W;
+            const unsigned n = q / (unsigned)H, iy = q - n * H;
+            const int oh = (int)iy + pad - ty, ow = (int)ix + pad - tx;
+            const bool ok = live && r < 16 && oh >= 0 && oh < OH && ow >= 0 && ow < OW;
+            gy[j] = dy[ok ? ((size_t)n * OH + oh) * OW + ow : 0];
+            gy[j] = ok ? gy[j] : 0.f;  // a dead pixel's (valid) x meets a zero dy column
+        }
+        unsigned lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lo[i] = (d[2 * i] & 0xffffu) | (d[2 * i + 1] << 16);
+            hi[i] = (d[2 * i] >> 16) | (d[2 * i + 1] & 0xffff0000u);
+        }
+        const bf16x8 fb = to_bf16x8(gy);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(lo), fb, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(hi), fb, acc[1], 0, 0, 0);
+    }
+    // acc[a][i]: channel cb*64 + 2*(8*(i>>2) + 4h + (i&3)) + a, tap r
+    if (r < 16) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm[wv][r][2 * (8 * (i >> 2) + 4 * h + (i & 3)) + a] = acc[a][i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 64; i += NT) {
+        const int t = i >> 6, c = cb * 64 + (i & 63);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) v += sm[k][t][i & 63];
+        if (c < Creal) unsafeAtomicAdd(dw + (size_t)c * 16 + t, v);
+    }
+    if (blockIdx.x == 0) {
+        float bs = 0.f;
+        for (unsigned i = threadIdx.x; i < Mout; i += NT) bs += dy[i];
+        __syncthreads();
+        bs = block_sum_256(bs, &sm[0][0][0]);
+        if (threadIdx.x == 0) unsafeAtomicAdd(db, bs);
+    }
+}
+
 inline bool head_ok(int dtype, int C, int R, long long items) {
     const int g = C / (dtype == SF_BF16 ? 8 : 4);
     return R >= 1 && R <= 4 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 && R * R * C <= HEAD_MAX_W && g * R * R <= 1024 &&
@@ -1107,6 +1179,18 @@ extern "C" int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, 
         const RowSplit sp = split_rows_small(M, rpp * 8, 256);
         DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_bwd_weight_kernel<T>, dim3(sp.grid), dim3(NT), 0, s, (const T*)x, dy, dw,
                                              db, (unsigned)M, sp.per, C, Creal));
+        SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
+        return SF_OK;
+    }
+    if (dtype == SF_BF16 && R == 4 && C % 64 == 0 && (long long)N * H * W < 0x7fffffffLL) {
+        const long long Min = (long long)N * H * W;
+        long long nsplit = (Min + 1023) / 1024;  // >= 16 groups of 16 pixels per wave
+        if (nsplit > 32) nsplit = 32;
+        long long per = ((Min + nsplit - 1) / nsplit + 15) / 16 * 16;
+        nsplit = (Min + per - 1) / per;
+        hipLaunchKernelGGL(head_bwd_weight_mfma_kernel, dim3((unsigned)((C / 64) * nsplit)), dim3(NT), 0, s,
+                           (const bf16*)x, dy, dw, db, (unsigned)Min, (unsigned)per, (unsigned)M, H, W, C, Creal, pad, OH,
+                           OW, (int)nsplit);
         SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
         return SF_OK;
     }
