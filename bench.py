@@ -107,7 +107,7 @@ def main():
 
     for i in range(a.warmup):
         ld = step(i)
-    tags = ("conv3_dma_kernel", "dec_conv1_wgrad")
+    tags = ("conv3_dma_wide_kernel", "conv3_dma_kernel", "wgrad3_dma_kernel")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -130,11 +130,16 @@ def main():
     bad = trainer.saw_nan_or_inf()
 
     if rank == 0:
-        # dominant kernel: conv3_dma_kernel, the 3x3 forward / data-gradient conv (six launches per
-        # step: decoder conv1 and conv2, encoder conv2, forward and data gradient each).
-        # Algorithmic flops of a launch = 2 * N*H*W * C * K * 9, recorded with its HIP-event time.
-        n_l, ms_l, achieved = ops.timed_tflops("conv3_dma_kernel")
-        n_w, ms_w = ops.timed_ms("dec_conv1_wgrad")
+        # The three MFMA kernels of the 3x3 convolutions (every launch is timed with HIP events on the
+        # launch stream; algorithmic flops of a launch = 2 * N*H*W * Cin * Cout * 9 with the real
+        # channel counts).  conv3_dma_wide_kernel / conv3_dma_kernel are the two shapes of the
+        # persistent forward / data-gradient kernel, wgrad3_dma_kernel the weight gradient.  The
+        # roofline object is the one with the largest total time per step.
+        stats = {t: ops.timed_tflops(t) for t in tags}
+        dom = max(tags, key=lambda t: stats[t][0] * stats[t][1])
+        n_l, ms_l, achieved = stats[dom]
+        others = {t: {"launches": stats[t][0], "ms_per_launch": round(stats[t][1], 4), "TFLOP/s": round(stats[t][2], 2)}
+                  for t in tags if t != dom}
         out = {
             "metric": "train samples/sec (node) @10ch 200x200 T=5",
             "value": round(world * a.batch * a.steps / dt, 3), "unit": "samples/s",
@@ -145,8 +150,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv3_dma_kernel", "launches": n_l, "ms_per_launch": round(ms_l, 4),
-                         "other": {"wgrad3_dma_kernel (decoder conv1, 1.51 TFLOP/launch) ms": round(ms_w, 4)}},
+                         "kernel": dom, "launches": n_l, "ms_per_launch": round(ms_l, 4), "other": others},
             "final_loss": round(loss, 6), "nan_or_inf": bad,
         }
         if world == 1 and not a.no_cpu_baseline:

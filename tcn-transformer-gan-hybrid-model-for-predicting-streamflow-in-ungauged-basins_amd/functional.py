@@ -73,7 +73,7 @@ class EncoderFn(torch.autograd.Function):
             C = a.shape[-1]
             wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), False, Kpad, C)
             z = torch.empty((N, h, w, Kpad), device=x.device, dtype=cdtype)
-            ops.conv3x3(a, wp, z, Kpad)
+            ops.conv3x3(a, wp, z, Kpad, flop_c=wt.shape[1], flop_k=K)
             M = N * h * w
             ws = None
             if training:
@@ -117,7 +117,7 @@ class EncoderFn(torch.autograd.Function):
             if l > 0 or ctx.needs_input_grad[0]:
                 wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), True, C, Kpad)
                 da = torch.empty((N, h, w, C), device=dz.device, dtype=cdtype)
-                ops.conv3x3(dz, wT, da, C, dgrad=True)
+                ops.conv3x3(dz, wT, da, C, dgrad=True, flop_c=K, flop_k=cin_real)
                 if l > 0:
                     dy = da
                 else:
@@ -265,7 +265,7 @@ class DecoderFn(torch.autograd.Function):
         w2p = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), False, Hp, Hp)
         bp2 = _pad_vec(b2.detach(), Hp)
         h2 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
-        ops.conv3x3(h1, w2p, h2, Hp, bias=bp2, act=ops.ACT_RELU)
+        ops.conv3x3(h1, w2p, h2, Hp, bias=bp2, act=ops.ACT_RELU, flop_c=Hc, flop_k=Hc)
         w3c = w3.detach().contiguous()
         y = ops.conv_k1_fwd(h2, w3c, b3.detach().contiguous(), 1, 0)
         ctx.save_for_backward(src, h1, h2, w3c, w9)
@@ -286,7 +286,7 @@ class DecoderFn(torch.autograd.Function):
         db2 = ops.channel_sum(dz2, Hc)
         w2T = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), True, Hp, Hp)
         dz1 = torch.empty_like(h1)
-        ops.conv3x3(dz2, w2T, dz1, Hp, dgrad=True, aux=h1, aux_mode=1)
+        ops.conv3x3(dz2, w2T, dz1, Hp, dgrad=True, aux=h1, aux_mode=1, flop_c=Hc, flop_k=Hc)
         g = ops.upconv3_bwd(dz1, h, w, cdtype).view(B, h, w, 9 * Hp)
         # dW9[(t,k)][c] = sum_pixels g[pixel][(t,k)] * src[pixel][c]
         dw9 = torch.zeros((9 * Hp, C, 1, 1), device=dy.device, dtype=torch.float32)
@@ -390,8 +390,12 @@ class DiscriminatorFn(torch.autograd.Function):
         w5 = rest[18]
         grads: List[Optional[torch.Tensor]] = [None] * (2 + len(rest))
         y4 = acts[3]
-        dw5, db5 = ops.conv_k1_bwd_weight(y4, dout, w5.shape[1], 4, 1)
-        grads[2 + 18], grads[2 + 19] = dw5, db5
+        # parameter gradients are skipped as a whole when no parameter asks for one (the trainer
+        # turns them off for batches whose discriminator gradients would be zeroed unused)
+        need_w = any(ctx.needs_input_grad[3:])
+        if need_w:
+            dw5, db5 = ops.conv_k1_bwd_weight(y4, dout, w5.shape[1], 4, 1)
+            grads[2 + 18], grads[2 + 19] = dw5, db5
         dy = ops.conv_k1_bwd_data(dout, w5.detach().contiguous(), y4, 4, 1, relu_mask=False)
         for i in (2, 1, 0):
             wt, b, gamma = rest[6 * i], rest[6 * i + 1], rest[6 * i + 2]
@@ -399,11 +403,12 @@ class DiscriminatorFn(torch.autograd.Function):
             K, C = wt.shape[0], yin.shape[-1]
             ih, iw, oh, ow = yin.shape[1], yin.shape[2], z.shape[1], z.shape[2]
             dz, dgamma, dbeta = ops.bn_backward(2, z, dy, st, gamma.detach(), K, True)
-            dw = torch.empty_like(wt)
-            ops.wgrad4x4s2(yin, dz, dw)
-            db = ops.channel_sum(dz, K)
-            grads[2 + 6 * i], grads[2 + 6 * i + 1] = dw, db
-            grads[2 + 6 * i + 2], grads[2 + 6 * i + 3] = dgamma, dbeta
+            if need_w:
+                dw = torch.empty_like(wt)
+                ops.wgrad4x4s2(yin, dz, dw)
+                db = ops.channel_sum(dz, K)
+                grads[2 + 6 * i], grads[2 + 6 * i + 1] = dw, db
+                grads[2 + 6 * i + 2], grads[2 + 6 * i + 3] = dgamma, dbeta
             # data gradient: four parity classes of the transposed stride-2 conv
             dyin = torch.empty_like(yin)
             problems = []
@@ -414,8 +419,9 @@ class DiscriminatorFn(torch.autograd.Function):
                 problems.append((dz, wT, dyin, geom, C, yin if i == 0 else None, 2 if i == 0 else 0))
             ops.conv_fprop_batch(problems)   # the four parity classes in one launch
             dy = dyin
-        dw1, db1 = ops.dconv1_bwd_weight(x, dy)
-        grads[0], grads[1] = dw1, db1
+        if need_w:
+            dw1, db1 = ops.dconv1_bwd_weight(x, dy)
+            grads[0], grads[1] = dw1, db1
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.dconv1_bwd_data(dy, w1.detach().contiguous(), x.shape[2], x.shape[3])

@@ -207,7 +207,8 @@ def conv_fprop_batch(problems):
     _check(lib().sf_gemm_batch(n, descs, A, B, None, X if any_aux else None, O, _stream()), "sf_gemm_batch")
 
 
-def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0, tag=None):
+def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0, tag=None,
+            flop_c: Optional[int] = None, flop_k: Optional[int] = None):
     """3x3 stride-1 pad-1 conv (dgrad=False) or its data gradient (dgrad=True; wp packed
     transposed).  bf16 tensors with C % 16 == 0 take the LDS-patch kernel, everything else the
     generic implicit GEMM."""
@@ -232,7 +233,8 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
                                 aux_mode, code_of(out.dtype), _stream()), "sf_conv3x3")
         if rec is not None:
             e1.record()
-            rec.append((e0, e1, 2.0 * N * H * W * C * K * 9))
+            # algorithmic flops: real (unpadded) channel counts when the caller states them
+            rec.append((e0, e1, 2.0 * N * H * W * (flop_c or C) * (flop_k or K) * 9))
         return
     geom = conv_geom(N, H, W, C, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)))
     conv_fprop(x, wp, out, geom, K, bias=bias, act=act, aux=aux, aux_mode=aux_mode, tag=tag)
@@ -248,7 +250,7 @@ def wgrad3x3(x, dout, dw, tag=None):
         _dev(x, dout, dw)
         nbytes = int(lib().sf_wgrad3x3_workspace_bytes(N, H, W, K, Cin))
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-        rec = TIMED.get(tag) if tag is not None else None
+        rec = TIMED.get(tag if tag is not None else "wgrad3_dma_kernel")
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -256,7 +258,7 @@ def wgrad3x3(x, dout, dw, tag=None):
                                  K, Cin, _stream()), "sf_wgrad3x3")
         if rec is not None:
             e1.record()
-            rec.append((e0, e1))
+            rec.append((e0, e1, 2.0 * N * H * W * Cin * K * 9))
         return
     dw.zero_()
     geom = conv_geom(N, H, W, Cx, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)), cin_real=Cin, RS=9)

@@ -97,6 +97,7 @@ class Trainer:
             self.gan_loss_fn = GANLoss(lambda_gan=self.gan_weight, lambda_pixel=1.0)
             self.opt_d = FlatAdam(self.discriminator, lr * 0.2, betas=(0.5, 0.999))
         self.batch_idx = 0
+        self._d_req = True
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.world = dist.get_world_size() if self.distributed else 1
         self.nan_flag = torch.zeros(1, device=self.device, dtype=torch.int32)
@@ -133,6 +134,20 @@ class Trainer:
             w.wait()
         self._pending = []
 
+    def _d_grads_consumed(self, bi: int) -> bool:
+        """Discriminator gradients produced in batch `bi` are used by an optimiser step only if
+        the next stepping batch (the first bs >= bi with (bs+1) % accum == 0, where both gradient
+        sets are zeroed) is also a discriminator batch; otherwise they are zeroed unread, so the
+        step skips computing them.  Parameters, losses and BatchNorm buffers are unaffected."""
+        bs = bi + (self.accum - 1 - bi % self.accum)
+        return self.use_gan and bs % self.d_update_interval == 0
+
+    def _set_d_requires_grad(self, flag: bool):
+        if self._d_req != flag:
+            for p in self.discriminator.parameters():
+                p.requires_grad_(flag)
+            self._d_req = flag
+
     # ---- one batch ------------------------------------------------------------------------
     def train_step(self, images, output_image, station_positions, station_runoffs) -> Dict[str, torch.Tensor]:
         """One iteration of the reference's batch loop.  Returns loss tensors (no host sync)."""
@@ -141,6 +156,9 @@ class Trainer:
         stepping = (bi + 1) % self.accum == 0
         d_batch = self.use_gan and bi % self.d_update_interval == 0
         self._reduce_now = self.distributed and stepping
+        d_live = self._d_grads_consumed(bi)
+        if self.use_gan:
+            self._set_d_requires_grad(d_live)
         images = images.to(self.device, non_blocking=True)
         output_image = output_image.to(self.device, non_blocking=True)
         ops.nan_inf_flag(images.contiguous().float().view(-1), self.nan_flag)
@@ -157,12 +175,13 @@ class Trainer:
                 ld["total"] = loss_g
         (loss_g / self.accum).backward()
         if d_batch:
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp), torch.set_grad_enabled(d_live):
                 pred_real = self.discriminator(output_image)
                 pred_fake_d = self.discriminator(pred.detach())
                 loss_d = self.gan_loss_fn.discriminator_loss(pred_real, pred_fake_d)
                 ld["gan_d"] = loss_d
-            (loss_d / self.accum).backward()
+            if d_live:
+                (loss_d / self.accum).backward()
         if stepping:
             scale = 1.0
             if self.distributed:
