@@ -107,13 +107,15 @@ def main():
 
     for i in range(a.warmup):
         ld = step(i)
-    tags = ("conv3_dma_wide_kernel", "conv3_dma_kernel", "wgrad3_dma_kernel")
+    # HIP-event pairs cost GPU time, so inside the timed region only the launches of the dominant
+    # kernel are bracketed (3 per step); the other two MFMA kernels are timed in extra steps after it
+    dom = "conv3_dma_wide_kernel"
+    other_tags = ("conv3_dma_kernel", "wgrad3_dma_kernel")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    for t in tags:
-        ops.TIMED[t] = []
+    ops.TIMED[dom] = []
     t0 = time.perf_counter()
     for i in range(a.steps):
         ld = step(a.warmup + i)
@@ -128,18 +130,26 @@ def main():
         dt = float(t.item())
     loss = float(ld["total"])
     bad = trainer.saw_nan_or_inf()
+    dom_stats = ops.timed_tflops(dom)
+    del ops.TIMED[dom]
+    for t in other_tags:
+        ops.TIMED[t] = []
+    for i in range(3):
+        step(a.warmup + a.steps + i)
+    torch.cuda.synchronize()
 
     if rank == 0:
-        # The three MFMA kernels of the 3x3 convolutions (every launch is timed with HIP events on the
+        # The three MFMA kernels of the 3x3 convolutions, every launch timed with HIP events on the
         # launch stream; algorithmic flops of a launch = 2 * N*H*W * Cin * Cout * 9 with the real
-        # channel counts).  conv3_dma_wide_kernel / conv3_dma_kernel are the two shapes of the
-        # persistent forward / data-gradient kernel, wgrad3_dma_kernel the weight gradient.  The
-        # roofline object is the one with the largest total time per step.
-        stats = {t: ops.timed_tflops(t) for t in tags}
-        dom = max(tags, key=lambda t: stats[t][0] * stats[t][1])
-        n_l, ms_l, achieved = stats[dom]
-        others = {t: {"launches": stats[t][0], "ms_per_launch": round(stats[t][1], 4), "TFLOP/s": round(stats[t][2], 2)}
-                  for t in tags if t != dom}
+        # channel counts.  conv3_dma_wide_kernel / conv3_dma_kernel are the two shapes of the
+        # persistent forward / data-gradient kernel, wgrad3_dma_kernel the weight gradient (its
+        # event pair also spans the small slab-reduction launch that follows it).
+        n_l, ms_l, achieved = dom_stats
+        others = {}
+        for t in other_tags:
+            n_o, ms_o, tf_o = ops.timed_tflops(t)
+            others[t] = {"launches": n_o, "ms_per_launch": round(ms_o, 4), "TFLOP/s": round(tf_o, 2),
+                         "measured": "3 extra steps after the timed region"}
         out = {
             "metric": "train samples/sec (node) @10ch 200x200 T=5",
             "value": round(world * a.batch * a.steps / dt, 3), "unit": "samples/s",

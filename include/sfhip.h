@@ -218,6 +218,13 @@ int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* aux, void* 
 /* dw f32 [1,Creal,R,R], db f32 [1] (zeroed here) */
 int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, float* dw, float* db, int N,
                           int H, int W, int C, int Creal, int R, int pad, void* stream);
+/* Backward of ReLU -> Conv2d(C,1,1)+bias (src/model/decoder.py:151-152) in one pass over x (the
+ * ReLU output, NHWC dtype [M,C]) and dy (f32 [M]): dx[p][c] = dy[p]*w[c]*(x[p][c] > 0) (dtype),
+ * dw[c] = sum_p dy[p]*x[p][c], db = sum_p dy[p], dsum[c] = sum_p dx[p][c] (the bias gradient of
+ * the conv under the ReLU).  dw, dsum f32 [Creal], db f32 [1]; C / (16-byte chunk) a power of two. */
+int sf_conv_k1_bwd_fused(const void* x, int dtype, const float* dy, const float* w, void* dx,
+                         float* dw, float* db, float* dsum, long long M, int C, int Creal,
+                         void* stream);
 
 /* ---- temporal modules ---------------------------------------------------------------- */
 /* One post-LN nn.TransformerEncoderLayer (relu FFN, batch_first) forward / backward for

@@ -724,6 +724,66 @@ __global__ __launch_bounds__(NT) void pw1_bwd_weight_kernel(const T* __restrict_
     reduce_phases_atomic<1>(acc + EPC, G, rpp, sm, db, [&](int gq, int v) -> long long { return gq == 0 ? 0 : -1; });
 }
 
+// Everything the backward of ReLU -> Conv2d(C,1,1) needs, in one pass over x (the ReLU output)
+// and dy: dx[p][c] = dy[p] * w[c] * (x[p][c] > 0), dw[c] = sum_p dy[p] * x[p][c], db = sum_p dy[p]
+// and dsum[c] = sum_p dx[p][c] (of the values as stored, i.e. rounded to T): the bias gradient
+// of the conv that produced x.
+template <typename T>
+__global__ __launch_bounds__(NT) void pw1_bwd_fused_kernel(const T* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ w, T* __restrict__ dx,
+                                                           float* __restrict__ dw, float* __restrict__ db,
+                                                           float* __restrict__ dsum, unsigned M, unsigned per, int C,
+                                                           int Creal) {
+    constexpr int EPC = ElemTraits<T>::EPC, U = 8;
+    __shared__ float sm[8 * NT];
+    const int G = C / EPC, rpp = NT / G;
+    const int cg = threadIdx.x % G, phase = threadIdx.x / G;
+    float wv[EPC], accw[EPC + 1], accs[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        wv[e] = cg * EPC + e < Creal ? w[cg * EPC + e] : 0.f;
+        accw[e] = accs[e] = 0.f;
+    }
+    accw[EPC] = 0.f;
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
+    for (unsigned r = r0 + phase; r < r1; r += rpp * U) {
+        uint4 raw[U];
+        float g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * rpp;
+            const bool ok = rr < r1;
+            const float gv = dy[ok ? rr : r];
+            g[u] = ok ? gv : 0.f;
+            raw[u] = *reinterpret_cast<const uint4*>(ok ? (const void*)(x + (size_t)rr * C + cg * EPC) : (const void*)&g_zero16s);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned rr = r + u * rpp;
+            float f[EPC], o[EPC];
+            decode16<T>(raw[u], f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                accw[e] += g[u] * f[e];
+                o[e] = from_f32<T>(f[e] > 0.f ? g[u] * wv[e] : 0.f);
+                accs[e] += to_f32(from_f32<T>(o[e]));
+            }
+            accw[EPC] += g[u];
+            if (rr < r1) store_chunk<T>(dx + (size_t)rr * C + cg * EPC, o);
+        }
+    }
+    reduce_phases_atomic<EPC>(accw, G, rpp, sm, dw, [&](int gq, int v) -> long long {
+        const int c = gq * EPC + v;
+        return c < Creal ? (long long)c : -1;
+    });
+    reduce_phases_atomic<1>(accw + EPC, G, rpp, sm, db, [&](int gq, int v) -> long long { return gq == 0 ? 0 : -1; });
+    reduce_phases_atomic<EPC>(accs, G, rpp, sm, dsum, [&](int gq, int v) -> long long {
+        const int c = gq * EPC + v;
+        return c < Creal ? (long long)c : -1;
+    });
+}
+
 // ------------------------------------------------------------------ RxR conv to one channel
 // (PatchGAN head, R = 4, stride 1).  Weights sit in LDS as [tap][channel]; loads of a work item
 // are issued together with clamped / zero-chunk addresses; 32-bit indices.
@@ -1210,5 +1270,25 @@ extern "C" int sf_conv_k1_bwd_weight(const void* x, int dtype, const float* dy, 
                                              (const T*)x, dy, dw, db, N, H, W, C, Creal, R, pad, OH, OW));
     }
     SF_LAUNCH_CHECK("sf_conv_k1_bwd_weight");
+    return SF_OK;
+}
+
+extern "C" int sf_conv_k1_bwd_fused(const void* x, int dtype, const float* dy, const float* w, void* dx, float* dw,
+                                    float* db, float* dsum, long long M, int C, int Creal, void* stream) {
+    SF_REQUIRE(x && dy && w && dx && dw && db && dsum, "sf_conv_k1_bwd_fused: null argument");
+    SF_REQUIRE(dtype == SF_BF16 || dtype == SF_F32, "sf_conv_k1_bwd_fused: bad dtype %d", dtype);
+    SF_REQUIRE(M > 0 && Creal > 0 && Creal <= C && pw1_ok(dtype, C, 1, 0, M),
+               "sf_conv_k1_bwd_fused: C / chunk must be a power of two <= 64 (C=%d)", C);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * Creal, s) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(dsum, 0, sizeof(float) * Creal, s) != hipSuccess) {
+        sf_set_error("sf_conv_k1_bwd_fused: memset failed");
+        return SF_ELAUNCH;
+    }
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const RowSplit sp = split_rows_small(M, (NT / (C / epc)) * 8, 512);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_bwd_fused_kernel<T>, dim3(sp.grid), dim3(NT), 0, s, (const T*)x, dy, w, (T*)dx,
+                                         dw, db, dsum, (unsigned)M, sp.per, C, Creal));
+    SF_LAUNCH_CHECK("sf_conv_k1_bwd_fused");
     return SF_OK;
 }

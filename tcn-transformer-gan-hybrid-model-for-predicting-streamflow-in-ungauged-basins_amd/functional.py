@@ -279,11 +279,14 @@ class DecoderFn(torch.autograd.Function):
         w1, w2 = ctx.weights
         B, C, h, w, OH, OW, Hc, Hp, cdtype = ctx.dims
         dy = dy.contiguous().float()
-        dw3, db3 = ops.conv_k1_bwd_weight(h2, dy, Hc, 1, 0)
-        dz2 = ops.conv_k1_bwd_data(dy, w3c, h2, 1, 0, relu_mask=True)
+        if ops.conv_k1_bwd_fused_ok(h2):
+            dz2, dw3, db3, db2 = ops.conv_k1_bwd_fused(h2, dy, w3c, Hc)
+        else:
+            dw3, db3 = ops.conv_k1_bwd_weight(h2, dy, Hc, 1, 0)
+            dz2 = ops.conv_k1_bwd_data(dy, w3c, h2, 1, 0, relu_mask=True)
+            db2 = ops.channel_sum(dz2, Hc)
         dw2 = torch.empty_like(w2)
         ops.wgrad3x3(h1, dz2, dw2)
-        db2 = ops.channel_sum(dz2, Hc)
         w2T = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), True, Hp, Hp)
         dz1 = torch.empty_like(h1)
         ops.conv3x3(dz2, w2T, dz1, Hp, dgrad=True, aux=h1, aux_mode=1, flop_c=Hc, flop_k=Hc)

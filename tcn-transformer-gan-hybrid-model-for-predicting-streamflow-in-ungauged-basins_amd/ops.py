@@ -65,7 +65,7 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
-           "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_transformer_save_floats",
+           "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
            "sf_bce_logits", "sf_adam", "sf_nan_inf_flag"]
@@ -524,6 +524,26 @@ def conv_k1_bwd_weight(x, dy, Creal, R, pad):
     _check(lib().sf_conv_k1_bwd_weight(_p(x), code_of(x.dtype), _p(dy), _p(dw), _p(db), N, H, W, C, Creal, R, pad,
                                        _stream()), "sf_conv_k1_bwd_weight")
     return dw, db
+
+
+def conv_k1_bwd_fused_ok(x: torch.Tensor) -> bool:
+    g = x.shape[-1] // epc(code_of(x.dtype))
+    return 1 <= g <= 64 and (g & (g - 1)) == 0 and x.numel() // x.shape[-1] < 2 ** 31 - 1
+
+
+def conv_k1_bwd_fused(x, dy, w, Creal):
+    """Backward of ReLU -> 1x1 conv to one channel in one pass: (dx, dw [1,Creal,1,1], db [1],
+    dsum [Creal] = channel sums of dx)."""
+    _dev(x, dy, w)
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    dw = torch.empty((1, Creal, 1, 1), device=x.device, dtype=torch.float32)
+    db = torch.empty(1, device=x.device, dtype=torch.float32)
+    dsum = torch.empty(Creal, device=x.device, dtype=torch.float32)
+    _check(lib().sf_conv_k1_bwd_fused(_p(x), code_of(x.dtype), _p(dy), _p(w), _p(dx), _p(dw), _p(db), _p(dsum), _c_ll(M),
+                                      C, Creal, _stream()), "sf_conv_k1_bwd_fused")
+    return dx, dw, db, dsum
 
 
 # ------------------------------------------------------------------------------ temporal
