@@ -5,9 +5,11 @@ It reproduces the reference's step semantics exactly (generator loss = combined 
 gan_weight * BCE(D(pred), 1) back-propagated THROUGH an unfrozen discriminator; discriminator
 loss every third batch on top; both optimisers step on (batch_idx+1) % accum == 0, the
 discriminator's only when batch_idx % 3 == 0; then both gradient sets are zeroed) and adds
-what the reference lacks: parameters / gradients / Adam moments live in flat buffers so that
-one fused kernel launch updates a whole network, and data-parallel gradient averaging over
-RCCL with the two 134 MB Linear weights reduced as soon as their gradients exist.
+what the reference lacks: parameters and Adam moments live in flat buffers so that one fused
+kernel launch updates a whole network, gradients are taken as the backward kernels produce them
+(no per-parameter accumulate launches), and data-parallel gradient averaging over RCCL reduces
+the two 134 MB Linear weight gradients in place as soon as they exist and everything else as
+one flat buffer.
 """
 from __future__ import annotations
 
@@ -24,58 +26,75 @@ _ALIGN = 64  # floats: every parameter starts on a 256-byte boundary of the flat
 
 
 class FlatAdam:
-    """All parameters of one network as views into one flat f32 buffer (same for gradients and
-    Adam moments); step() is a single sf_adam launch (torch.optim.Adam defaults: eps 1e-8, no
-    weight decay, src/train.py:80-91)."""
+    """Adam (torch.optim.Adam defaults: eps 1e-8, no weight decay, src/train.py:80-91) over flat
+    f32 buffers: parameters and both moments of one network live in one buffer each (parameters
+    are views into it), so a whole network is updated by one sf_adam launch.
 
-    def __init__(self, module: nn.Module, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    Gradients are not views: with .grad unset, autograd hands every parameter the tensor its
+    backward kernel produced instead of launching an accumulate kernel per parameter per backward
+    pass.  gather() then copies the small gradients into one flat buffer (a multi-tensor copy;
+    that buffer is also what data-parallel ranks all-reduce in one call), while parameters of at
+    least `big_numel` elements sit at the end of the layout and are updated straight from their
+    own gradient tensors (and all-reduced in place)."""
+
+    def __init__(self, module: nn.Module, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, big_numel: int = 1 << 22):
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.small = [p for p in params if p.numel() < big_numel]
+        self.big = [p for p in params if p.numel() >= big_numel]
+        self.params = self.small + self.big
         offs, total = [], 0
         for p in self.params:
             offs.append(total)
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.n_small = offs[len(self.small)] if self.big else total
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self.m = torch.zeros(total, device=dev, dtype=torch.float32)
         self.v = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.gsmall = torch.zeros(self.n_small, device=dev, dtype=torch.float32)
         self.ranges = []
         for p, o in zip(self.params, offs):
             n = p.numel()
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view(p.shape)
-            p.grad = self.grad[o:o + n].view(p.shape)
+            p.grad = None
             self.ranges.append((o, n))
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
 
+    def gather(self):
+        """Small gradients -> self.gsmall (zeros for a parameter that received none)."""
+        dst, src = [], []
+        for p, (o, n) in zip(self.small, self.ranges):
+            if p.grad is None:
+                self.gsmall[o:o + n].zero_()
+            else:
+                dst.append(self.gsmall[o:o + n].view(p.shape))
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
     def step(self, grad_scale: float = 1.0):
+        """One Adam update from the gathered small gradients and the big parameters' own gradient
+        tensors (a big parameter without a gradient is skipped, like torch.optim.Adam does)."""
         self.t += 1
-        ops.adam(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                 grad_scale)
+        b1, b2 = self.betas
+        S = self.n_small
+        if S:
+            ops.adam(self.flat[:S], self.gsmall, self.m[:S], self.v[:S], self.lr, b1, b2, self.eps, self.t, grad_scale)
+        for p, (o, n) in zip(self.big, self.ranges[len(self.small):]):
+            if p.grad is not None:
+                ops.adam(self.flat[o:o + n], p.grad.contiguous().view(-1), self.m[o:o + n], self.v[o:o + n], self.lr,
+                         b1, b2, self.eps, self.t, grad_scale)
 
     def zero_grad(self):
-        self.grad.zero_()
+        for p in self.params:
+            p.grad = None
 
     def range_of(self, p: torch.Tensor):
         for q, r in zip(self.params, self.ranges):
             if q is p:
                 return r
         raise KeyError("parameter not managed by this optimiser")
-
-
-def reduce_ranges(flat_grad: torch.Tensor, skip: Sequence = ()) -> List:
-    """Sum-all-reduce (async) every element of a flat gradient buffer that lies outside the
-    `skip` ranges [(offset, numel), ...] -- those were already reduced from a hook -- in as few
-    calls as the gaps allow.  Skipped ranges are rounded up to the buffer's alignment, like the
-    parameter slots themselves.  Returns the work handles.  Device-agnostic (RCCL or gloo)."""
-    total = flat_grad.numel()
-    works = []
-    pos = 0
-    for (o, n) in sorted(skip) + [(total, 0)]:
-        if o > pos:
-            works.append(dist.all_reduce(flat_grad[pos:o], async_op=True))
-        pos = max(pos, o + (n + _ALIGN - 1) // _ALIGN * _ALIGN)
-    return works
 
 
 class Trainer:
@@ -109,25 +128,14 @@ class Trainer:
     # ---- data parallel ------------------------------------------------------------------
     def _install_early_reduce(self):
         """The two 262144-wide Linear weights are 95 % of the gradient bytes; their gradients are
-        complete long before the encoder's backward finishes, so their all-reduce is issued from
-        a post-accumulate hook and overlaps with the remaining backward kernels."""
-        big = [self.model.temporal_to_spatial.weight]
-        ip = getattr(self.model.temporal_module, "input_proj", None)
-        if ip is not None:
-            big.append(ip.weight)
-        self._big_ranges = []
-        for p in big:
-            o, n = self.opt_g.range_of(p)
-            self._big_ranges.append((o, n))
-
-            def hook(param, o=o, n=n):
+        complete long before the encoder's backward finishes, so each is all-reduced in place
+        from a post-accumulate hook and overlaps with the remaining backward kernels."""
+        for p in self.opt_g.big:
+            def hook(param):
                 if self._reduce_now:
-                    self._pending.append(dist.all_reduce(self.opt_g.grad[o:o + n], async_op=True))
+                    self._pending.append(dist.all_reduce(param.grad, async_op=True))
 
             p.register_post_accumulate_grad_hook(hook)
-
-    def _reduce_rest(self, opt: FlatAdam, skip: Sequence = ()):
-        self._pending += reduce_ranges(opt.grad, skip)
 
     def _wait_reduces(self):
         for w in self._pending:
@@ -184,10 +192,15 @@ class Trainer:
                 (loss_d / self.accum).backward()
         if stepping:
             scale = 1.0
+            self.opt_g.gather()
+            if d_batch:
+                self.opt_d.gather()
             if self.distributed:
-                self._reduce_rest(self.opt_g, self._big_ranges)
+                # big gradients are already on their way (hooks); everything else is one buffer
+                self._pending.append(dist.all_reduce(self.opt_g.gsmall, async_op=True))
                 if d_batch:
-                    self._reduce_rest(self.opt_d)
+                    self._pending += [dist.all_reduce(self.opt_d.gsmall, async_op=True)]
+                    self._pending += [dist.all_reduce(p.grad, async_op=True) for p in self.opt_d.big if p.grad is not None]
                 self._wait_reduces()
                 scale = 1.0 / self.world
             self.opt_g.step(scale)

@@ -1,6 +1,7 @@
-"""Data-parallel gradient exchange on CPU: two gloo ranks, the flat-buffer layout of
-training.FlatAdam and the early-hook + remaining-ranges reduction of training.Trainer
-(src/train.py has no DP path; this is row (e) of the hot-path contract)."""
+"""Data-parallel gradient exchange on CPU: two gloo ranks, the layout of training.FlatAdam
+(small gradients gathered into one flat buffer, big ones reduced in place from a
+post-accumulate hook) as training.Trainer uses it (src/train.py has no DP path; this is row (e)
+of the hot-path contract)."""
 import os
 import socket
 
@@ -20,6 +21,11 @@ def _free_port():
     return port
 
 
+def _net():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Linear(7, 130), nn.Linear(130, 5), nn.Linear(5, 3))
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -28,83 +34,73 @@ def _worker(rank, world, port, out):
         sf = load_pkg()
         import importlib
         training = importlib.import_module(sf.__name__ + ".training")
-        torch.manual_seed(0)
-        net = nn.Sequential(nn.Linear(7, 130), nn.Linear(130, 5), nn.Linear(5, 3))
-        opt = training.FlatAdam(net, lr=1e-3)
-        # parameters and gradients are views into the flat buffers, 64-float aligned
+        net = _net()
+        opt = training.FlatAdam(net, lr=1e-3, big_numel=900)   # the 7x130 weight counts as big
+        assert [p.numel() for p in opt.big] == [910]
+        # parameters are views into the flat buffer, 64-float aligned, big ones last; no .grad yet
         for p, (o, n) in zip(opt.params, opt.ranges):
-            assert o % 64 == 0 and p.data.data_ptr() == opt.flat[o:o + n].data_ptr()
-            assert p.grad.data_ptr() == opt.grad[o:o + n].data_ptr()
-        big = net[0].weight
-        bo, bn = opt.range_of(big)
+            assert o % 64 == 0 and p.data.data_ptr() == opt.flat[o:o + n].data_ptr() and p.grad is None
+        assert opt.range_of(opt.big[0])[0] == opt.n_small
         pending = []
 
         def hook(param):
-            pending.append(dist.all_reduce(opt.grad[bo:bo + bn], async_op=True))
+            pending.append(dist.all_reduce(param.grad, async_op=True))
 
-        big.register_post_accumulate_grad_hook(hook)
+        opt.big[0].register_post_accumulate_grad_hook(hook)
         x = torch.full((4, 7), float(rank + 1))
         net(x).sum().backward()          # the hook fires for the big weight during backward
         assert len(pending) == 1
-        pending += training.reduce_ranges(opt.grad, [(bo, bn)])
+        opt.gather()
+        pending.append(dist.all_reduce(opt.gsmall, async_op=True))
         for w in pending:
             w.wait()
-        out[rank] = opt.grad.clone()
+        out[rank] = (opt.gsmall.clone(), opt.big[0].grad.clone(), [r for r in opt.ranges])
+        opt.zero_grad()
+        assert all(p.grad is None for p in net.parameters())
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_flat_gradient_reduce():
+def test_two_rank_gradient_reduce():
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    g0, g1 = out[0], out[1]
-    assert torch.equal(g0, g1)           # every element reduced, none twice on one rank only
+    (s0, b0, ranges), (s1, b1, _) = out[0], out[1]
+    assert torch.equal(s0, s1) and torch.equal(b0, b1)   # every element reduced, on both ranks alike
     # expected: the sum over ranks of the single-process gradients
-    torch.manual_seed(0)
-    net = nn.Sequential(nn.Linear(7, 130), nn.Linear(130, 5), nn.Linear(5, 3))
-    want = [torch.zeros_like(p) for p in net.parameters()]
+    net = _net()
+    params = list(net.parameters())
+    want = [torch.zeros_like(p) for p in params]
     for r in range(world):
         net.zero_grad()
         net(torch.full((4, 7), float(r + 1))).sum().backward()
-        for w, p in zip(want, net.parameters()):
+        for w, p in zip(want, params):
             w += p.grad
-    pos = 0
-    for w in want:
-        n = w.numel()
-        torch.testing.assert_close(g0[pos:pos + n].view(w.shape), w, rtol=1e-6, atol=1e-6)
-        pos += (n + 63) // 64 * 64
-    assert pos == g0.numel()
+    small = [w for w in want if w.numel() < 900]
+    big = [w for w in want if w.numel() >= 900]
+    torch.testing.assert_close(b0, big[0], rtol=1e-6, atol=1e-6)
+    covered = 0
+    for w, (o, n) in zip(small, ranges):
+        assert n == w.numel()
+        torch.testing.assert_close(s0[o:o + n].view(w.shape), w, rtol=1e-6, atol=1e-6)
+        covered += n
+    assert float(s0.abs().sum()) > 0 and covered == sum(w.numel() for w in small)
 
 
-def test_reduce_ranges_cuts():
-    """reduce_ranges covers exactly the complement of the skipped (alignment-rounded) ranges."""
+def test_gather_zero_fills_missing_gradients():
+    """A parameter that received no gradient contributes zeros, not last step's values."""
     import importlib
     sf = load_pkg()
     training = importlib.import_module(sf.__name__ + ".training")
-    calls = []
-
-    class W:
-        def wait(self):
-            pass
-
-    def fake(t, async_op=False):
-        calls.append((t.storage_offset(), t.numel()))
-        return W()
-
-    real = dist.all_reduce
-    dist.all_reduce = fake
-    try:
-        g = torch.zeros(1024)
-        training.reduce_ranges(g, [(128, 100), (512, 64)])
-        assert calls == [(0, 128), (256, 256), (576, 448)]
-        calls.clear()
-        training.reduce_ranges(g, [(0, 64)])
-        assert calls == [(64, 960)]
-        calls.clear()
-        training.reduce_ranges(g, [])
-        assert calls == [(0, 1024)]
-    finally:
-        dist.all_reduce = real
+    net = _net()
+    opt = training.FlatAdam(net, lr=1e-3)
+    net(torch.ones(2, 7)).sum().backward()
+    opt.gather()
+    assert float(opt.gsmall.abs().sum()) > 0
+    opt.zero_grad()
+    net[2].weight.grad = torch.ones_like(net[2].weight)
+    opt.gather()
+    o, n = opt.range_of(net[2].weight)
+    assert float(opt.gsmall[o:o + n].sum()) == n and float(opt.gsmall.abs().sum()) == n
