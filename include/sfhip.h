@@ -172,6 +172,29 @@ int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* dy, int dy_d
 int sf_channel_sum(const void* x, int dtype, long long M, int C, int Creal, float* out, double* ws,
                    void* stream);
 
+/* ---- first encoder layer without its pre-activation tensor --------------------------
+ * Conv2d(C<=16,K,3,padding=1,bias=False) -> BatchNorm2d -> ReLU -> MaxPool2d(2)
+ * (src/model/cnn_encoder.py:42-50, layer 0), bf16.  x NHWC [N,H,W,16] (channels zero-padded to
+ * 16); w packed [K][9][16] (sf_pack_conv_weight); K = 128 or 256.  The conv output is
+ * recomputed in each pass and never stored:
+ *   sf_enc1_stats: ws[0..K) = sum, ws[K..2K) = sum of squares of the bf16-rounded conv output
+ *                  (ws zeroed here; feed sf_bn_finalize with M = N*H*W)
+ *   sf_enc1_fwd:   y[N,H/2,W/2,K] = maxpool2x2(relu(conv*scale + shift)) */
+int sf_enc1_stats(const void* x, const void* w, double* ws, int N, int H, int W, int K, void* stream);
+int sf_enc1_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y,
+                int N, int H, int W, int K, void* stream);
+/*   sf_enc1_bwd:   from dy (gradient wrt the pooled map, NHWC bf16 [N,H/2,W/2,K]) the gradients
+ *                  dw f32 [K,Creal,3,3], dgamma, dbeta f32 [K] of conv weight and BatchNorm
+ *                  (training != 0: batch statistics took part in the forward); the input gets
+ *                  no gradient.  Creal <= 14 real input channels; ws: workspace of
+ *                  sf_enc1_bwd_workspace_bytes bytes (per-workgroup partial results, summed in
+ *                  a fixed order: reproducible). */
+size_t sf_enc1_bwd_workspace_bytes(int N, int H, int W, int K, int Creal);
+int sf_enc1_bwd(const void* x, const void* w, const void* dy, const float* scale, const float* shift,
+                const float* mean, const float* invstd, int training, float* dw, float* dgamma,
+                float* dbeta, float* ws, size_t ws_bytes, int N, int H, int W, int K, int Creal,
+                void* stream);
+
 /* ---- bilinear resize, align_corners=False (src/model/decoder.py:165-170, src/loss.py:49-54) */
 /* src NHWC f32 [B,h,w,C] -> dst NHWC (dtype) [B,OH,OW,C]; C == Cpad */
 int sf_bilinear_fwd(const void* src, int src_dtype, void* dst, int dtype, int B, int C, int h,

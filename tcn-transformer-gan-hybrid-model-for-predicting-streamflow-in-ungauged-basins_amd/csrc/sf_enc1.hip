@@ -1,0 +1,506 @@
+// First encoder layer without its pre-activation tensor: Conv2d(C<=16, K, 3, padding=1, bias=False)
+// -> BatchNorm2d -> ReLU -> MaxPool2d(2) (src/model/cnn_encoder.py:42-50, layer 0).
+//
+// With at most 16 (padded) input channels the conv is one MFMA reduction step per tap: 9 MFMAs
+// per 32 pixels x 32 output channels.  Its K-channel output at full resolution, however, is the
+// largest tensor of the whole model (51 MB per sample in bf16) and the reference formulation
+// walks it six times (write, statistics, normalise+pool, two backward passes, weight gradient).
+// Here the conv is recomputed from the 16-channel input wherever its output is needed and the
+// output never leaves the registers:
+//   sf_enc1_stats : conv -> round to bf16 -> per-channel sum / sum of squares
+//   sf_enc1_fwd   : conv -> round to bf16 -> scale/shift -> ReLU -> 2x2 max -> pooled map
+//   sf_enc1_bwd   : conv -> ... -> routed pooled gradient dzm; accumulates the correlations
+//                   A1 = dzm^T xp and A2 = z^T xp (xp = input patches), the patch sums S and the
+//                   BatchNorm sums, from which a finalize kernel forms the weight / gamma / beta
+//                   gradients (the input needs no gradient).
+// The MFMA runs with D[pixel][channel]: a lane owns one output channel, its 16 accumulator
+// registers are 16 pixels ordered so that four consecutive registers are one 2x2 pooling window
+// -- channel sums, the window maximum and the arg-max routing are all in-lane.
+#include "sf_common.h"
+#include "../../include/sfhip.h"
+
+namespace {
+
+constexpr int E_NT = 256;                    // 4 waves
+constexpr int E_TH = 16, E_TW = 16;          // output pixels per tile (8 x 8 pooling windows)
+constexpr int E_PW = E_TW + 2, E_PP = (E_TH + 2) * E_PW;   // halo patch
+constexpr int E_ROWB = 32;                   // bytes per LDS row: 16 bf16 channels
+constexpr int E_PCHUNKS = E_PP * 2;          // 16-byte chunks of a patch
+constexpr int E_PLOADS = (E_PCHUNKS + E_NT - 1) / E_NT;
+
+enum { E_STATS = 0, E_FWD = 1 };
+
+struct E1Params {
+    const bf16* x;       // [N,H,W,16]
+    const bf16* w;       // packed [K][9][16]
+    int N, H, W, K;
+    int tiles_x, tiles_y, ntiles;
+    double* ws;          // stats: [2K] sums, sums of squares
+    const float* scale;  // fwd
+    const float* shift;
+    bf16* y;             // fwd: [N,H/2,W/2,K]
+};
+
+__device__ __forceinline__ bf16x8 to_bf16x8(const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    return v;
+}
+
+struct TilePos { int n, y0, x0; };
+__device__ __forceinline__ TilePos tile_pos(const E1Params& p, int t) {
+    TilePos tp;
+    const int tx = t % p.tiles_x, r = t / p.tiles_x;
+    tp.x0 = tx * E_TW;
+    tp.y0 = (r % p.tiles_y) * E_TH;
+    tp.n = r / p.tiles_y;
+    return tp;
+}
+
+// the workgroup's copy of the weights: LDS [tap][k][16 channels]
+__device__ __forceinline__ void stage_weights(const E1Params& p, char* sW) {
+    const int chunks = p.K * 9 * 2;
+    for (int i = threadIdx.x; i < chunks; i += E_NT) {
+        const int half = i & 1, row = i >> 1;        // row = k * 9 + tap in the packed tensor
+        const int k = row / 9, tap = row - k * 9;
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w) + (size_t)i * 16);
+        *reinterpret_cast<uint4*>(sW + ((tap * p.K + k) * 2 + half) * 16) = v;
+    }
+}
+
+// halo patch of a tile -> registers (buffer loads: an offset past the end returns zeros, which is
+// how the padding ring and tiles hanging over the image edge are filled)
+__device__ __forceinline__ void load_patch(const E1Params& p, __amdgpu_buffer_rsrc_t rs, const TilePos& tp, bool live,
+                                           uint4* regs) {
+#pragma unroll
+    for (int j = 0; j < E_PLOADS; ++j) {
+        const int c = threadIdx.x + j * E_NT;
+        const int half = c & 1, row = c >> 1;
+        const int py = row / E_PW, px = row - py * E_PW;
+        const int gy = tp.y0 - 1 + py, gx = tp.x0 - 1 + px;
+        const bool ok = live && c < E_PCHUNKS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const int off = ok ? (((tp.n * p.H + gy) * p.W + gx) * 2 + half) * 16 : (int)0x80000000;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        regs[j] = *reinterpret_cast<const uint4*>(&v);
+    }
+}
+__device__ __forceinline__ void store_patch(char* sP, const uint4* regs) {
+#pragma unroll
+    for (int j = 0; j < E_PLOADS; ++j) {
+        const int c = threadIdx.x + j * E_NT;
+        if (c < E_PCHUNKS) *reinterpret_cast<uint4*>(sP + c * 16) = regs[j];
+    }
+}
+
+template <int MODE, int NKT>
+__global__ __launch_bounds__(E_NT) void enc1_kernel(E1Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;                               // 9 * K * 32 bytes
+    char* sP = smem + 9 * p.K * E_ROWB;            // E_PP * 32 bytes
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stage_weights(p, sW);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (unsigned)((size_t)p.N * p.H * p.W * E_ROWB), 0x00020000);
+
+    // lane constants.  MFMA row r of a row tile = window r >> 2 (along x), position r & 3 in it.
+    const int a_px = 2 * (r >> 2) + (r & 1), a_py = (r >> 1) & 1;
+    const int a_off = (a_py * E_PW + a_px) * E_ROWB + 16 * h;     // + (2 rt + ty) * PW * 32 + tx * 32
+    const int b_off = r * E_ROWB + 16 * h;                        // + (tap * K + kt * 32) * 32
+
+    float ssum[NKT], ssq[NKT], sc[NKT], sf[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        ssum[kt] = ssq[kt] = 0.f;
+        if (MODE == E_FWD) { sc[kt] = p.scale[kt * 32 + r]; sf[kt] = p.shift[kt * 32 + r]; }
+    }
+    const int PH = p.H / 2, PWd = p.W / 2;
+
+    uint4 pre[E_PLOADS];
+    int t = blockIdx.x;
+    TilePos tp = tile_pos(p, t < p.ntiles ? t : 0);
+    load_patch(p, rs, tp, t < p.ntiles, pre);
+    for (; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();                 // everyone is done with the previous patch (and sW is staged)
+        store_patch(sP, pre);
+        __syncthreads();
+        const TilePos cur = tp;
+        const int tn = t + gridDim.x;
+        tp = tile_pos(p, tn < p.ntiles ? tn : 0);
+        load_patch(p, rs, tp, tn < p.ntiles, pre);   // next tile's patch flies under this tile's MFMAs
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rt = wave * 2 + q;             // window row of the tile
+            bf16x8 fa[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                fa[tap] = *reinterpret_cast<const bf16x8*>(sP + a_off + ((2 * rt + tap / 3) * E_PW + tap % 3) * E_ROWB);
+            // validity of the lane's 16 pixels: register i -> window 2 (i >> 2) + h, position i & 3
+            const int gy0 = cur.y0 + 2 * rt;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + b_off + (tap * p.K + kt * 32) * E_ROWB);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap], fb, acc, 0, 0, 0);
+                }
+                if (MODE == E_STATS) {
+                    float s = 0.f, q2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int gy = gy0 + ((i >> 1) & 1), gx = cur.x0 + 2 * (2 * (i >> 2) + h) + (i & 1);
+                        const float z = (float)(bf16)acc[i];
+                        const bool ok = gy < p.H && gx < p.W;
+                        s += ok ? z : 0.f;
+                        q2 += ok ? z * z : 0.f;
+                    }
+                    ssum[kt] += s;
+                    ssq[kt] += q2;
+                } else {
+                    const int wy = (cur.y0 >> 1) + rt;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float mx = 0.f;                       // max with 0 == ReLU, then max
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float z = (float)(bf16)acc[4 * g + e];
+                            const float v = z * sc[kt] + sf[kt];
+                            mx = v > mx ? v : mx;
+                        }
+                        const int wx = (cur.x0 >> 1) + 2 * g + h;
+                        if (wy < PH && wx < PWd)
+                            p.y[(((size_t)cur.n * PH + wy) * PWd + wx) * p.K + kt * 32 + r] = (bf16)mx;
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == E_STATS) {
+        // lanes l and l + 32 hold the same channel; then the four waves; one atomic per channel
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sP);   // [2][4 waves][K]
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const float s = ssum[kt] + __shfl_xor(ssum[kt], 32, 64);
+            const float q2 = ssq[kt] + __shfl_xor(ssq[kt], 32, 64);
+            if (h == 0) {
+                red[wave * p.K + kt * 32 + r] = s;
+                red[(4 + wave) * p.K + kt * 32 + r] = q2;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * p.K; i += E_NT) {
+            const int which = i / p.K, k = i - which * p.K;
+            double v = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) v += (double)red[(which * 4 + w2) * p.K + k];
+            unsafeAtomicAdd(p.ws + i, v);
+        }
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------
+// Wave w of a workgroup owns output-channel tile kt = 4 * blockIdx.y + w (its nine weight
+// fragments stay in registers) and walks all 8 window rows of every tile of the workgroup:
+// conv -> z (bf16-rounded, zero outside the image) -> BatchNorm -> arg-max routing of the pooled
+// gradient -> dzm.  Register i of a lane is reduction index 8h + (i & 7) of MFMA step i >> 3, so
+// z and dzm are A operands as they stand; the B operand xp[pixel][(tap, c)] is gathered from the
+// LDS patch with 2-byte reads (one column (tap, c) per lane, c < Creal only: 9 * Creal columns).
+// Accumulated per wave: A1 = dzm^T xp, A2 = z^T xp (rows = channels), the patch sums S (an MFMA
+// with the pixel-validity mask as A; wave w does column tile w) and the two BatchNorm sums.
+// Every workgroup stores its partial results to its own slab; enc1_bwd_finalize_kernel adds the
+// slabs in a fixed order and forms the gradients.
+struct E1Bwd {
+    E1Params c;
+    const bf16* dy;       // [N,H/2,W/2,K] gradient wrt the pooled map
+    const float* mean; const float* invstd;
+    float* slab;          // [gridDim.x][slab_floats]
+    int Creal, ncols;     // ncols = 9 * Creal
+};
+// slab layout (floats): A1 [K][NCT*32], A2 [K][NCT*32], S [NCT*32], m1 [K], m2 [K]
+__host__ __device__ inline size_t slab_floats(int K, int nct) { return (size_t)2 * K * nct * 32 + nct * 32 + 2 * K; }
+
+template <int NCT>
+__global__ __launch_bounds__(E_NT) void enc1_bwd_kernel(E1Bwd a) {
+    const E1Params& p = a.c;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sP = smem;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kt = blockIdx.y * 4 + wave;
+    const bool active = kt * 32 < p.K;
+    const int k = active ? kt * 32 + r : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (unsigned)((size_t)p.N * p.H * p.W * E_ROWB), 0x00020000);
+    const int PH = p.H / 2, PWd = p.W / 2;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (unsigned)((size_t)p.N * PH * PWd * p.K * 2), 0x00020000);
+
+    // conv weights of this wave's channel tile: B operand of D[pixel][channel]
+    bf16x8 fw[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        fw[tap] = *reinterpret_cast<const bf16x8*>(p.w + ((size_t)k * 9 + tap) * 16 + 8 * h);
+    const float sc = p.scale[k], sf = p.shift[k], mu = a.mean[k], is = a.invstd[k];
+
+    const int a_px = 2 * (r >> 2) + (r & 1), a_py = (r >> 1) & 1;
+    const int a_off = (a_py * E_PW + a_px) * E_ROWB + 16 * h;
+    // gather base of the lane's column (tap, c) in each column tile, + 2 window columns for h = 1
+    int g_off[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        int col = ct * 32 + r;
+        if (col >= a.ncols) col = 0;
+        const int tap = col / a.Creal, ch = col - tap * a.Creal;
+        g_off[ct] = ((tap / 3) * E_PW + tap % 3) * E_ROWB + 2 * ch + 2 * h * E_ROWB;
+    }
+
+    f32x16 accA1[NCT], accA2[NCT], accS;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accA1[ct][i] = accA2[ct][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accS[i] = 0.f;
+    float m1 = 0.f, m2 = 0.f;
+
+    uint4 pre[E_PLOADS];
+    int t = blockIdx.x;
+    TilePos tp = tile_pos(p, t < p.ntiles ? t : 0);
+    load_patch(p, rs, tp, t < p.ntiles, pre);
+    for (; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();
+        store_patch(sP, pre);
+        __syncthreads();
+        const TilePos cur = tp;
+        const int tn = t + gridDim.x;
+        tp = tile_pos(p, tn < p.ntiles ? tn : 0);
+        load_patch(p, rs, tp, tn < p.ntiles, pre);
+        if (!active) continue;
+        // pooled gradient of the lane's 4 windows of a window row (zero outside the pooled map)
+        auto load_dy = [&](int rt, unsigned short* g) {
+            const int wy = (cur.y0 >> 1) + rt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int wx = (cur.x0 >> 1) + 2 * q + h;
+                const bool ok = wy < PH && wx < PWd;
+                const int off = ok ? (int)((((cur.n * PH + wy) * PWd + wx) * p.K + k) * 2) : (int)0x80000000;
+                g[q] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rdy, off, 0, 0);
+            }
+        };
+        unsigned short gq[2][4];
+        load_dy(0, gq[0]);
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+            if (rt + 1 < 8) load_dy(rt + 1, gq[(rt + 1) & 1]);
+            const char* prow = sP + 2 * rt * E_PW * E_ROWB;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(prow + a_off + ((tap / 3) * E_PW + tap % 3) * E_ROWB);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fw[tap], acc, 0, 0, 0);
+            }
+            // z, validity, routing
+            const int gy0 = cur.y0 + 2 * rt;
+            float z[16], dz[16], vm[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float best = 0.f;
+                int arg = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e;
+                    const int gy = gy0 + (e >> 1), gx = cur.x0 + 2 * (2 * g + h) + (e & 1);
+                    const bool ok = gy < p.H && gx < p.W;
+                    const float zz = ok ? (float)(bf16)acc[i] : 0.f;
+                    z[i] = zz;
+                    vm[i] = ok ? 1.f : 0.f;
+                    const float v = zz * sc + sf;
+                    if (e == 0) { best = v; arg = 0; }
+                    else if (v > best) { best = v; arg = e; }
+                }
+                const unsigned gbits = (unsigned)gq[rt & 1][g] << 16;
+                const float gv = best > 0.f ? __uint_as_float(gbits) : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = e == arg ? gv : 0.f;
+                    dz[4 * g + e] = d;
+                    m1 += d;
+                    m2 += d * ((z[4 * g + e] - mu) * is);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 fz = to_bf16x8(z + 8 * s2), fd = to_bf16x8(dz + 8 * s2), fv = to_bf16x8(vm + 8 * s2);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    // xp of the 8 pixels (2 windows) of this half-step for the lane's column
+                    unsigned short xs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int win = 4 * s2 + 2 * (j >> 2), e = j & 3;     // + h via g_off
+                        const int off = ((e >> 1) * E_PW + 2 * win + (e & 1)) * E_ROWB;
+                        xs[j] = *reinterpret_cast<const unsigned short*>(prow + g_off[ct] + off);
+                    }
+                    unsigned xw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xw[q] = (unsigned)xs[2 * q] | ((unsigned)xs[2 * q + 1] << 16);
+                    const bf16x8 fx = *reinterpret_cast<const bf16x8*>(xw);
+                    accA1[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd, fx, accA1[ct], 0, 0, 0);
+                    accA2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz, fx, accA2[ct], 0, 0, 0);
+                    if (ct == wave) accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fx, accS, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- slab: every element written (zeros from idle waves), no atomics
+    float* slab = a.slab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * slab_floats(p.K, NCT);
+    const int ncp = NCT * 32;
+    if (active) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                slab[(size_t)row * ncp + ct * 32 + r] = accA1[ct][i];
+                slab[(size_t)(p.K + row) * ncp + ct * 32 + r] = accA2[ct][i];
+            }
+        const float t1 = m1 + __shfl_xor(m1, 32, 64), t2 = m2 + __shfl_xor(m2, 32, 64);
+        if (h == 0) {
+            slab[(size_t)2 * p.K * ncp + ncp + k] = t1;
+            slab[(size_t)2 * p.K * ncp + ncp + p.K + k] = t2;
+        }
+    }
+    // S: every row of accS holds the same sums; the workgroup of channel group 0 records them
+    if (wave < NCT && h == 0) slab[(size_t)2 * p.K * ncp + wave * 32 + r] = active ? accS[0] : 0.f;
+}
+
+// dW[k][c][tap] = scale[k] * (A1 - m1/M * S - m2/M * invstd[k] * (A2 - mean[k] * S))   (training)
+//              = scale[k] * A1                                                          (eval)
+// dgamma = m2, dbeta = m1.  One thread per (k, column); slabs are added in index order.
+__global__ void enc1_bwd_finalize_kernel(const float* __restrict__ slabs, int nslabs, int ky /* slab groups per K */,
+                                         int K, int nct, int Creal, double inv_m, int training,
+                                         const float* __restrict__ scale, const float* __restrict__ mean,
+                                         const float* __restrict__ invstd, float* __restrict__ dw,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int ncp = nct * 32, ncols = 9 * Creal;
+    const size_t sf_ = slab_floats(K, nct);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= K * ncols) return;
+    const int k = idx / ncols, col = idx - k * ncols;
+    const int grp = k / 128;                 // the slab group (blockIdx.y) that owns this channel
+    double a1 = 0.0, a2 = 0.0, s = 0.0, m1 = 0.0, m2 = 0.0;
+    for (int i = 0; i < nslabs; ++i) {
+        const float* sl = slabs + ((size_t)grp * nslabs + i) * sf_;
+        a1 += (double)sl[(size_t)k * ncp + col];
+        a2 += (double)sl[(size_t)(K + k) * ncp + col];
+        m1 += (double)sl[(size_t)2 * K * ncp + ncp + k];
+        m2 += (double)sl[(size_t)2 * K * ncp + ncp + K + k];
+        s += (double)slabs[(size_t)i * sf_ + (size_t)2 * K * ncp + col];   // group 0 holds S
+    }
+    (void)ky;
+    const int tap = col / Creal, c = col - tap * Creal;
+    double g = a1;
+    if (training) g = a1 - m1 * inv_m * s - m2 * inv_m * (double)invstd[k] * (a2 - (double)mean[k] * s);
+    dw[((size_t)k * Creal + c) * 9 + tap] = (float)((double)scale[k] * g);
+    if (col == 0) { dgamma[k] = (float)m2; dbeta[k] = (float)m1; }
+}
+
+int fill(E1Params& p, const char* who, const void* x, const void* w, int N, int H, int W, int K) {
+    if (!x || !w || N <= 0 || H < 2 || W < 2 || (K != 128 && K != 256) ||
+        (long long)N * H * W * E_ROWB >= 0x7fffffffLL) {
+        sf_set_error("%s: unsupported shape N=%d H=%d W=%d K=%d (K must be 128 or 256)", who, N, H, W, K);
+        return SF_EINVAL;
+    }
+    p.x = (const bf16*)x; p.w = (const bf16*)w;
+    p.N = N; p.H = H; p.W = W; p.K = K;
+    p.tiles_x = (W + E_TW - 1) / E_TW;
+    p.tiles_y = (H + E_TH - 1) / E_TH;
+    p.ntiles = N * p.tiles_x * p.tiles_y;
+    p.ws = nullptr; p.scale = p.shift = nullptr; p.y = nullptr;
+    return SF_OK;
+}
+
+template <int MODE>
+int launch(const E1Params& p, hipStream_t s, const char* who) {
+    const size_t lds = (size_t)9 * p.K * E_ROWB + (size_t)E_PP * E_ROWB + (MODE == E_STATS ? 0 : 0);
+    int grid = p.ntiles < 768 ? p.ntiles : 768;
+    void (*kern)(E1Params) = nullptr;
+    kern = p.K == 128 ? enc1_kernel<MODE, 4> : enc1_kernel<MODE, 8>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        sf_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", who, lds);
+        return SF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(E_NT), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sf_set_error("%s: launch failed: %s", who, hipGetErrorString(e)); return SF_ELAUNCH; }
+    return SF_OK;
+}
+
+}  // namespace
+
+extern "C" int sf_enc1_stats(const void* x, const void* w, double* ws, int N, int H, int W, int K, void* stream) {
+    E1Params p;
+    if (int rc = fill(p, "sf_enc1_stats", x, w, N, H, W, K)) return rc;
+    SF_REQUIRE(ws, "sf_enc1_stats: null workspace");
+    SF_REQUIRE(8 * K * sizeof(float) <= (size_t)E_PP * E_ROWB, "sf_enc1_stats: K too large for the reduction buffer");
+    p.ws = ws;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * K, (hipStream_t)stream) != hipSuccess) {
+        sf_set_error("sf_enc1_stats: memset failed");
+        return SF_ELAUNCH;
+    }
+    return launch<E_STATS>(p, (hipStream_t)stream, "sf_enc1_stats");
+}
+
+extern "C" int sf_enc1_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H,
+                           int W, int K, void* stream) {
+    E1Params p;
+    if (int rc = fill(p, "sf_enc1_fwd", x, w, N, H, W, K)) return rc;
+    SF_REQUIRE(scale && shift && y, "sf_enc1_fwd: null argument");
+    p.scale = scale; p.shift = shift; p.y = (bf16*)y;
+    return launch<E_FWD>(p, (hipStream_t)stream, "sf_enc1_fwd");
+}
+
+extern "C" size_t sf_enc1_bwd_workspace_bytes(int N, int H, int W, int K, int Creal) {
+    const int nct = (9 * Creal + 31) / 32;
+    const long long ntiles = (long long)N * ((W + E_TW - 1) / E_TW) * ((H + E_TH - 1) / E_TH);
+    const long long gx = ntiles < 512 ? ntiles : 512;
+    return sizeof(float) * slab_floats(K, nct) * (size_t)gx * (size_t)((K + 127) / 128);
+}
+
+extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, int training, float* dw, float* dgamma, float* dbeta,
+                           float* ws, size_t ws_bytes, int N, int H, int W, int K, int Creal, void* stream) {
+    E1Bwd a;
+    if (int rc = fill(a.c, "sf_enc1_bwd", x, w, N, H, W, K)) return rc;
+    SF_REQUIRE(dy && scale && shift && mean && invstd && dw && dgamma && dbeta && ws, "sf_enc1_bwd: null argument");
+    SF_REQUIRE(Creal >= 1 && Creal <= 14, "sf_enc1_bwd: 1..14 real input channels supported (got %d)", Creal);
+    SF_REQUIRE((long long)N * (H / 2) * (W / 2) * K * 2 < 0x7fffffffLL, "sf_enc1_bwd: pooled gradient exceeds 2 GiB");
+    const size_t need = sf_enc1_bwd_workspace_bytes(N, H, W, K, Creal);
+    SF_REQUIRE(ws_bytes >= need, "sf_enc1_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    a.c.scale = scale; a.c.shift = shift;
+    a.dy = (const bf16*)dy; a.mean = mean; a.invstd = invstd; a.slab = ws;
+    a.Creal = Creal; a.ncols = 9 * Creal;
+    const int nct = (a.ncols + 31) / 32;
+    const int gx = a.c.ntiles < 512 ? a.c.ntiles : 512, gy = (K + 127) / 128;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)E_PP * E_ROWB;
+    switch (nct) {
+        case 1: hipLaunchKernelGGL(enc1_bwd_kernel<1>, dim3(gx, gy), dim3(E_NT), lds, s, a); break;
+        case 2: hipLaunchKernelGGL(enc1_bwd_kernel<2>, dim3(gx, gy), dim3(E_NT), lds, s, a); break;
+        case 3: hipLaunchKernelGGL(enc1_bwd_kernel<3>, dim3(gx, gy), dim3(E_NT), lds, s, a); break;
+        default: hipLaunchKernelGGL(enc1_bwd_kernel<4>, dim3(gx, gy), dim3(E_NT), lds, s, a); break;
+    }
+    const int total = K * a.ncols;
+    hipLaunchKernelGGL(enc1_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ws, gx, gy, K, nct, Creal,
+                       1.0 / ((double)N * H * W), training, scale, mean, invstd, dw, dgamma, dbeta);
+    SF_LAUNCH_CHECK("sf_enc1_bwd");
+    return SF_OK;
+}

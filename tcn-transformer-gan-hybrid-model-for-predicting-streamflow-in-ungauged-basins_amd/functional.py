@@ -72,15 +72,28 @@ class EncoderFn(torch.autograd.Function):
             Kpad = ops.roundup(K, 8)
             C = a.shape[-1]
             wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), False, Kpad, C)
+            M = N * h * w
+            if (l == 0 and L > 1 and not ctx.needs_input_grad[0] and K == Kpad and wt.shape[1] <= 14
+                    and ops.enc1_ok(a, K) and not ops.FORCE_GENERIC_CONV):
+                # first layer: the conv output (the model's largest tensor) is never stored; the
+                # statistics, the pooled activation and later the gradients each recompute it
+                ws = None
+                if training:
+                    ws = torch.empty(2 * K, device=x.device, dtype=torch.float64)
+                    ops.enc1_stats(a, wp, K, ws)
+                st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, training)
+                saved.append((a, None, st, (h, w), wp))
+                a = ops.enc1_fwd(a, wp, st, K)
+                h, w = h // 2, w // 2
+                continue
             z = torch.empty((N, h, w, Kpad), device=x.device, dtype=cdtype)
             ops.conv3x3(a, wp, z, Kpad, flop_c=wt.shape[1], flop_k=K)
-            M = N * h * w
             ws = None
             if training:
                 ws = torch.empty(2 * Kpad, device=x.device, dtype=torch.float64)
                 ops.bn_stats(z, M, Kpad, ws)
             st = ops.bn_finalize(ws, M, Kpad, K, gamma.detach(), beta.detach(), rm, rv, training)
-            saved.append((a, z, st, (h, w)))
+            saved.append((a, z, st, (h, w), None))
             if l < L - 1:
                 a = ops.bn_relu_maxpool_fwd(z, st)
                 h, w = h // 2, w // 2
@@ -106,9 +119,13 @@ class EncoderFn(torch.autograd.Function):
         dx = None
         for l in range(L - 1, -1, -1):
             wt, gamma = params[5 * l], params[5 * l + 1]
-            a, z, st, (h, w) = ctx.saved[l]
-            K, Kpad, C = wt.shape[0], z.shape[-1], a.shape[-1]
+            a, z, st, (h, w), wp = ctx.saved[l]
             cin_real = wt.shape[1]
+            if z is None:   # fused first layer: weight / BatchNorm gradients straight from the input
+                dw, dgamma, dbeta = ops.enc1_bwd(a, wp, dy, st, training, wt.shape[0], cin_real)
+                grads[5 * l], grads[5 * l + 1], grads[5 * l + 2] = dw, dgamma, dbeta
+                continue
+            K, Kpad, C = wt.shape[0], z.shape[-1], a.shape[-1]
             mode = 1 if l == L - 1 else 0
             dz, dgamma, dbeta = ops.bn_backward(mode, z, dy, st, gamma.detach(), K, training, oh, ow)
             dw = torch.empty_like(wt)

@@ -57,6 +57,7 @@ def lib():
         L.sf_lstm_save_floats.restype = ctypes.c_size_t
         L.sf_wgrad3x3_workspace_bytes.restype = ctypes.c_size_t
         L.sf_wgrad4x4s2_workspace_bytes.restype = ctypes.c_size_t
+        L.sf_enc1_bwd_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 
@@ -64,7 +65,7 @@ def lib():
 EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
-           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
+           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
            "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
@@ -376,6 +377,42 @@ def bn_relu_avgpool_fwd(x, st, Creal, OH, OW, out_dtype):
     _check(lib().sf_bn_relu_avgpool_fwd(_p(x), code_of(x.dtype), _p(st[0]), _p(st[1]), _p(y), code_of(out_dtype), N, H,
                                         W, C, Creal, OH, OW, _stream()), "sf_bn_relu_avgpool_fwd")
     return y
+
+
+def enc1_ok(x: torch.Tensor, K: int) -> bool:
+    """The fused first-layer kernels take bf16 NHWC input with 16 (padded) channels."""
+    N, H, W, _ = x.shape
+    return (x.dtype == torch.bfloat16 and x.shape[-1] == 16 and K in (128, 256) and H >= 2 and W >= 2
+            and x.numel() * 2 < 2 ** 31 - 1 and N * (H // 2) * (W // 2) * K * 2 < 2 ** 31 - 1)
+
+
+def enc1_stats(x, wp, K, ws):
+    _dev(x, wp, ws)
+    N, H, W, _ = x.shape
+    _check(lib().sf_enc1_stats(_p(x), _p(wp), _p(ws), N, H, W, K, _stream()), "sf_enc1_stats")
+
+
+def enc1_fwd(x, wp, st, K):
+    _dev(x, wp, st)
+    N, H, W, _ = x.shape
+    y = torch.empty((N, H // 2, W // 2, K), device=x.device, dtype=torch.bfloat16)
+    _check(lib().sf_enc1_fwd(_p(x), _p(wp), _p(st[0]), _p(st[1]), _p(y), N, H, W, K, _stream()), "sf_enc1_fwd")
+    return y
+
+
+def enc1_bwd(x, wp, dy, st, training, K, Creal):
+    """(dw [K,Creal,3,3], dgamma, dbeta) of the fused first encoder layer; st = bn_finalize rows."""
+    _dev(x, wp, dy, st)
+    N, H, W, _ = x.shape
+    nbytes = int(lib().sf_enc1_bwd_workspace_bytes(N, H, W, K, Creal))
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty((K, Creal, 3, 3), device=x.device, dtype=torch.float32)
+    dgamma = torch.empty(K, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty(K, device=x.device, dtype=torch.float32)
+    _check(lib().sf_enc1_bwd(_p(x), _p(wp), _p(dy), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), int(training), _p(dw),
+                             _p(dgamma), _p(dbeta), _p(ws), ctypes.c_size_t(nbytes), N, H, W, K, Creal, _stream()),
+           "sf_enc1_bwd")
+    return dw, dgamma, dbeta
 
 
 def bn_lrelu_fwd(x, st):

@@ -605,3 +605,48 @@ def test_upconv3_against_interpolate_then_conv(sf, dtype):
         close(dw, wr.grad.numpy(), tol_g)
         close(dsrc.permute(0, 3, 1, 2), xr.grad.numpy(), tol_g)
         close(db, dzsum.numpy(), tol_g)
+
+
+def test_enc1_fused_layer_against_separate_kernels(sf):
+    """sf_enc1_stats / sf_enc1_fwd / sf_enc1_bwd (first encoder layer with the conv recomputed in
+    every pass, its output never stored) against the separate conv3x3 -> bn_stats ->
+    bn_relu_maxpool -> bn_backward -> wgrad3x3 kernels on the same bf16 operands.  Statistics to
+    2e-4, pooled output to one bf16 rounding step (the two conv kernels sum the taps in different
+    orders), gradients to 2e-2 of the max (the separate path rounds the pre-activation gradient
+    to bf16, the fused one does not; a flipped arg-max moves single elements).  Odd sizes,
+    partial tiles, training and eval statistics."""
+    ops = sf.ops
+    torch.manual_seed(7)
+    for (N, H, W, Cin, K, training) in [(2, 32, 32, 10, 128, True), (3, 37, 53, 10, 128, True), (1, 200, 200, 14, 128, True),
+                                        (2, 17, 16, 3, 256, True), (2, 40, 24, 10, 128, False)]:
+        x = torch.zeros(N, H, W, 16, device=DEV)
+        x[..., :Cin] = torch.randn(N, H, W, Cin, device=DEV)
+        x = x.to(torch.bfloat16)
+        wt = torch.randn(K, Cin, 3, 3, device=DEV) / (3.0 * Cin ** 0.5)
+        wp = ops.pack_conv_weight(wt, torch.bfloat16, list(range(9)), False, K, 16)
+        z = torch.empty(N, H, W, K, device=DEV, dtype=torch.bfloat16)
+        ops.conv3x3(x, wp, z, K)
+        M = N * H * W
+        ws_ref = torch.empty(2 * K, device=DEV, dtype=torch.float64)
+        ops.bn_stats(z, M, K, ws_ref)
+        ws = torch.empty(2 * K, device=DEV, dtype=torch.float64)
+        ops.enc1_stats(x, wp, K, ws)
+        assert float((ws[K:] - ws_ref[K:]).abs().max() / ws_ref[K:].abs().max()) < 2e-4
+        assert float((ws[:K] - ws_ref[:K]).abs().max() / (ws_ref[K:].abs().max() * M) ** 0.5) < 2e-3
+        gamma, beta = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+        rm, rv = torch.randn(K, device=DEV) * 0.05, torch.rand(K, device=DEV) + 0.5
+        st = ops.bn_finalize(ws_ref if training else None, M, K, K, gamma, beta, rm, rv, training)
+        a_ref = ops.bn_relu_maxpool_fwd(z, st)
+        a = ops.enc1_fwd(x, wp, st, K)
+        assert a.shape == a_ref.shape
+        close(a.float(), a_ref.float().cpu().numpy(), 1e-2)
+        assert float((a.float() - a_ref.float()).abs().mean()) < 1e-3 * float(a_ref.float().abs().mean() + 1e-6)
+        # backward
+        dy = torch.randn(N, H // 2, W // 2, K, device=DEV).to(torch.bfloat16)
+        dz, dgamma_ref, dbeta_ref = ops.bn_backward(0, z, dy, st, gamma, K, training)
+        dw_ref = torch.empty(K, Cin, 3, 3, device=DEV)
+        ops.wgrad3x3(x, dz, dw_ref)
+        dw, dgamma, dbeta = ops.enc1_bwd(x, wp, dy, st, training, K, Cin)
+        close(dbeta, dbeta_ref.cpu().numpy(), 2e-3)
+        close(dgamma, dgamma_ref.cpu().numpy(), 2e-3)
+        close(dw, dw_ref.cpu().numpy(), 2e-2)
