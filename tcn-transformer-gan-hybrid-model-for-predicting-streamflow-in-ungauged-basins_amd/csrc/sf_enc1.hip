@@ -18,6 +18,7 @@
 // -- channel sums, the window maximum and the arg-max routing are all in-lane.
 #include "sf_common.h"
 #include "../../include/sfhip.h"
+#include <type_traits>
 
 namespace {
 
@@ -46,6 +47,13 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const float* f) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
     return v;
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 t;
+    t[0] = (bf16)a; t[1] = (bf16)b;
+    return *reinterpret_cast<const unsigned*>(&t);
 }
 
 struct TilePos { int n, y0, x0; };
@@ -94,7 +102,7 @@ __device__ __forceinline__ void store_patch(char* sP, const uint4* regs) {
 }
 
 template <int MODE, int NKT>
-__global__ __launch_bounds__(E_NT) void enc1_kernel(E1Params p) {
+__global__ __launch_bounds__(E_NT, 3) void enc1_kernel(E1Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;                               // 9 * K * 32 bytes
     char* sP = smem + 9 * p.K * E_ROWB;            // E_PP * 32 bytes
@@ -140,6 +148,8 @@ __global__ __launch_bounds__(E_NT) void enc1_kernel(E1Params p) {
             const int gy0 = cur.y0 + 2 * rt;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
+                // keeps the weight reads of later channel tiles from being hoisted up here (registers)
+                __builtin_amdgcn_sched_barrier(0);
                 f32x16 acc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -210,10 +220,12 @@ __global__ __launch_bounds__(E_NT) void enc1_kernel(E1Params p) {
 // gradient -> dzm.  Register i of a lane is reduction index 8h + (i & 7) of MFMA step i >> 3, so
 // z and dzm are A operands as they stand; the B operand xp[pixel][(tap, c)] is gathered from the
 // LDS patch with 2-byte reads (one column (tap, c) per lane, c < Creal only: 9 * Creal columns).
-// Accumulated per wave: A1 = dzm^T xp, A2 = z^T xp (rows = channels), the patch sums S (an MFMA
-// with the pixel-validity mask as A; wave w does column tile w) and the two BatchNorm sums.
-// Every workgroup stores its partial results to its own slab; enc1_bwd_finalize_kernel adds the
-// slabs in a fixed order and forms the gradients.
+// Accumulated per wave: A1 = dzm^T xp, A2 = z^T xp (rows = channels) and the two BatchNorm sums.
+// The tile's pooled gradients go through LDS (16-byte loads, prefetched a tile ahead like the
+// patch).  Every workgroup stores its partial results to its own slab; the patch sums
+// S[(tap, c)] = sum_p xp[p][(tap, c)] come from enc1_input_sums_kernel (whole-image, border-row,
+// border-column and corner sums of the input); enc1_bwd_finalize_kernel adds the slabs in a fixed
+// order and forms the gradients.
 struct E1Bwd {
     E1Params c;
     const bf16* dy;       // [N,H/2,W/2,K] gradient wrt the pooled map
@@ -221,11 +233,13 @@ struct E1Bwd {
     float* slab;          // [gridDim.x][slab_floats]
     int Creal, ncols;     // ncols = 9 * Creal
 };
-// slab layout (floats): A1 [K][NCT*32], A2 [K][NCT*32], S [NCT*32], m1 [K], m2 [K]
-__host__ __device__ inline size_t slab_floats(int K, int nct) { return (size_t)2 * K * nct * 32 + nct * 32 + 2 * K; }
+// slab layout (floats): A1 [K][NCT*32], A2 [K][NCT*32], m1 [K], m2 [K]
+__host__ __device__ inline size_t slab_floats(int K, int nct) { return (size_t)2 * K * nct * 32 + 2 * K; }
+constexpr int E_DCH = 64 * 16;                       // 16-byte chunks of a tile's pooled gradient (128 channels)
+constexpr int E_DLOADS = E_DCH / E_NT;
 
 template <int NCT>
-__global__ __launch_bounds__(E_NT) void enc1_bwd_kernel(E1Bwd a) {
+__global__ __launch_bounds__(E_NT, 2) void enc1_bwd_kernel(E1Bwd a) {
     const E1Params& p = a.c;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sP = smem;
@@ -239,12 +253,34 @@ __global__ __launch_bounds__(E_NT) void enc1_bwd_kernel(E1Bwd a) {
     const int PH = p.H / 2, PWd = p.W / 2;
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.dy, 0, (unsigned)((size_t)p.N * PH * PWd * p.K * 2), 0x00020000);
-
-    // conv weights of this wave's channel tile: B operand of D[pixel][channel]
-    bf16x8 fw[9];
+    // pooled gradient of a tile (8 x 8 windows x this workgroup's 128 channels) -> registers -> LDS
+    auto load_dyt = [&](const TilePos& tq, bool live, uint4* regs) __attribute__((always_inline)) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-        fw[tap] = *reinterpret_cast<const bf16x8*>(p.w + ((size_t)k * 9 + tap) * 16 + 8 * h);
+        for (int j = 0; j < E_DLOADS; ++j) {
+            const int c = threadIdx.x + j * E_NT;
+            const int win = c >> 4, part = c & 15;
+            const int wy = (tq.y0 >> 1) + (win >> 3), wx = (tq.x0 >> 1) + (win & 7);
+            const bool ok = live && wy < PH && wx < PWd && blockIdx.y * 128 + part * 8 < p.K;
+            const int off = ok ? (((tq.n * PH + wy) * PWd + wx) * p.K + blockIdx.y * 128 + part * 8) * 2 : (int)0x80000000;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
+            regs[j] = *reinterpret_cast<const uint4*>(&v);
+        }
+    };
+
+    // conv weights of the workgroup's 128 channels: LDS [tap][128][16] (B operand of
+    // D[pixel][channel]; in registers they would cost 36 VGPRs the accumulators need)
+    char* sWb = smem + E_PP * E_ROWB;
+    char* sD = sWb + 9 * 128 * E_ROWB;                    // [64 windows][128 channels] bf16
+    const int d_off = ((h * 128) + wave * 32 + r) * 2;    // + (rt * 8 + 2 q) * 256
+    for (int i = threadIdx.x; i < 128 * 9 * 2; i += E_NT) {
+        const int half = i & 1, row = i >> 1;
+        const int kk = row / 9, tap = row - kk * 9;
+        const int kg = blockIdx.y * 128 + kk;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kg < p.K) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w) + ((size_t)kg * 9 + tap) * 32 + half * 16);
+        *reinterpret_cast<uint4*>(sWb + ((tap * 128 + kk) * 2 + half) * 16) = v;
+    }
+    const int w_off = (wave * 32 + r) * E_ROWB + 16 * h;   // + tap * 128 * 32
     const float sc = p.scale[k], sf = p.shift[k], mu = a.mean[k], is = a.invstd[k];
 
     const int a_px = 2 * (r >> 2) + (r & 1), a_py = (r >> 1) & 1;
@@ -259,44 +295,34 @@ __global__ __launch_bounds__(E_NT) void enc1_bwd_kernel(E1Bwd a) {
         g_off[ct] = ((tap / 3) * E_PW + tap % 3) * E_ROWB + 2 * ch + 2 * h * E_ROWB;
     }
 
-    f32x16 accA1[NCT], accA2[NCT], accS;
+    f32x16 accA1[NCT], accA2[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int i = 0; i < 16; ++i) accA1[ct][i] = accA2[ct][i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accS[i] = 0.f;
     float m1 = 0.f, m2 = 0.f;
 
-    uint4 pre[E_PLOADS];
+    uint4 pre[E_PLOADS], pred[E_DLOADS];
     int t = blockIdx.x;
     TilePos tp = tile_pos(p, t < p.ntiles ? t : 0);
     load_patch(p, rs, tp, t < p.ntiles, pre);
+    load_dyt(tp, t < p.ntiles, pred);
     for (; t < p.ntiles; t += gridDim.x) {
         __syncthreads();
         store_patch(sP, pre);
+#pragma unroll
+        for (int j = 0; j < E_DLOADS; ++j) *reinterpret_cast<uint4*>(sD + (threadIdx.x + j * E_NT) * 16) = pred[j];
         __syncthreads();
         const TilePos cur = tp;
         const int tn = t + gridDim.x;
         tp = tile_pos(p, tn < p.ntiles ? tn : 0);
         load_patch(p, rs, tp, tn < p.ntiles, pre);
+        load_dyt(tp, tn < p.ntiles, pred);
         if (!active) continue;
-        // pooled gradient of the lane's 4 windows of a window row (zero outside the pooled map)
-        auto load_dy = [&](int rt, unsigned short* g) {
-            const int wy = (cur.y0 >> 1) + rt;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int wx = (cur.x0 >> 1) + 2 * q + h;
-                const bool ok = wy < PH && wx < PWd;
-                const int off = ok ? (int)((((cur.n * PH + wy) * PWd + wx) * p.K + k) * 2) : (int)0x80000000;
-                g[q] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rdy, off, 0, 0);
-            }
-        };
-        unsigned short gq[2][4];
-        load_dy(0, gq[0]);
-#pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
-            if (rt + 1 < 8) load_dy(rt + 1, gq[(rt + 1) & 1]);
+        // tiles inside the image (all but the last tile row / column) skip every validity test
+        const bool full = cur.y0 + E_TH <= p.H && cur.x0 + E_TW <= p.W;
+        // one window row: conv, routing, correlations
+        auto process = [&](int rt, auto FULL) __attribute__((always_inline)) {
             const char* prow = sP + 2 * rt * E_PW * E_ROWB;
             f32x16 acc;
 #pragma unroll
@@ -304,42 +330,53 @@ __global__ __launch_bounds__(E_NT) void enc1_bwd_kernel(E1Bwd a) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(prow + a_off + ((tap / 3) * E_PW + tap % 3) * E_ROWB);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fw[tap], acc, 0, 0, 0);
+                const bf16x8 fw = *reinterpret_cast<const bf16x8*>(sWb + w_off + tap * 128 * E_ROWB);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fw, acc, 0, 0, 0);
             }
-            // z, validity, routing
+            __builtin_amdgcn_sched_barrier(0);
+            // Routing, window by window, on packed bf16 pairs: zp = (z0,z1) / (z2,z3) are A-operand
+            // dwords as they stand, and so are the routed gradients dp (the pooled gradient's 16
+            // bits in the arg-max position, zero elsewhere).
+            unsigned zp[8], dp[8];
             const int gy0 = cur.y0 + 2 * rt;
-            float z[16], dz[16], vm[16];
+            unsigned short gcur[4];     // pooled gradient of the lane's 4 windows (zero outside the pooled map)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gcur[q] = *reinterpret_cast<const unsigned short*>(sD + d_off + (rt * 8 + 2 * q) * 256);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float best = 0.f;
-                int arg = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * g + e;
-                    const int gy = gy0 + (e >> 1), gx = cur.x0 + 2 * (2 * g + h) + (e & 1);
-                    const bool ok = gy < p.H && gx < p.W;
-                    const float zz = ok ? (float)(bf16)acc[i] : 0.f;
-                    z[i] = zz;
-                    vm[i] = ok ? 1.f : 0.f;
-                    const float v = zz * sc + sf;
-                    if (e == 0) { best = v; arg = 0; }
-                    else if (v > best) { best = v; arg = e; }
+                unsigned p01 = pack_bf16x2(acc[4 * g], acc[4 * g + 1]), p23 = pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]);
+                if (!decltype(FULL)::value) {
+                    const int gx = cur.x0 + 2 * (2 * g + h);
+                    const unsigned mx = (gx < p.W ? 0xffffu : 0u) | (gx + 1 < p.W ? 0xffff0000u : 0u);
+                    const unsigned m01 = gy0 < p.H ? mx : 0u, m23 = gy0 + 1 < p.H ? mx : 0u;
+                    p01 &= m01; p23 &= m23;
                 }
-                const unsigned gbits = (unsigned)gq[rt & 1][g] << 16;
-                const float gv = best > 0.f ? __uint_as_float(gbits) : 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = e == arg ? gv : 0.f;
-                    dz[4 * g + e] = d;
-                    m1 += d;
-                    m2 += d * ((z[4 * g + e] - mu) * is);
-                }
+                zp[2 * g] = p01; zp[2 * g + 1] = p23;
+                const float z0 = __uint_as_float(p01 << 16), z1 = __uint_as_float(p01 & 0xffff0000u);
+                const float z2 = __uint_as_float(p23 << 16), z3 = __uint_as_float(p23 & 0xffff0000u);
+                const float v0 = z0 * sc + sf, v1 = z1 * sc + sf, v2 = z2 * sc + sf, v3 = z3 * sc + sf;
+                // first maximum in the order 0,1,2,3 (strict >), as a two-level tournament
+                const bool c1 = v1 > v0, c3 = v3 > v2;
+                const float b01 = c1 ? v1 : v0, zb01 = c1 ? z1 : z0;
+                const float b23 = c3 ? v3 : v2, zb23 = c3 ? z3 : z2;
+                const bool cf = b23 > b01;
+                const float best = cf ? b23 : b01, zbest = cf ? zb23 : zb01;
+                const unsigned g16 = best > 0.f ? (unsigned)gcur[g] : 0u;   // ReLU: no gradient through max <= 0
+                const float gv = __uint_as_float(g16 << 16);
+                m1 += gv;
+                m2 += gv * zbest;                    // sum dzm * z; centred and scaled at the end
+                const unsigned ghi = g16 << 16;
+                const unsigned s1 = c1 ? ghi : g16, s3 = c3 ? ghi : g16;
+                dp[2 * g] = cf ? 0u : s1;
+                dp[2 * g + 1] = cf ? s3 : 0u;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 fz = to_bf16x8(z + 8 * s2), fd = to_bf16x8(dz + 8 * s2), fv = to_bf16x8(vm + 8 * s2);
+                const bf16x8 fz = *reinterpret_cast<const bf16x8*>(zp + 4 * s2);
+                const bf16x8 fd = *reinterpret_cast<const bf16x8*>(dp + 4 * s2);
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
+                    __builtin_amdgcn_sched_barrier(0);
                     // xp of the 8 pixels (2 windows) of this half-step for the lane's column
                     unsigned short xs[8];
 #pragma unroll
@@ -354,11 +391,23 @@ __global__ __launch_bounds__(E_NT) void enc1_bwd_kernel(E1Bwd a) {
                     const bf16x8 fx = *reinterpret_cast<const bf16x8*>(xw);
                     accA1[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd, fx, accA1[ct], 0, 0, 0);
                     accA2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz, fx, accA2[ct], 0, 0, 0);
-                    if (ct == wave) accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fx, accS, 0, 0, 0);
                 }
             }
-        }
+        };
+        // two window rows per trip; not unrolled further: a fully unrolled tile needs more registers
+        // than two waves per SIMD have
+        auto run_tile = [&](auto FULL) __attribute__((always_inline)) {
+#pragma unroll 1
+            for (int rp = 0; rp < 4; ++rp) {
+                process(2 * rp, FULL);
+                process(2 * rp + 1, FULL);
+            }
+        };
+        if (full) run_tile(std::true_type{});
+        else run_tile(std::false_type{});
     }
+    // sum dzm * xhat = invstd * (sum dzm * z - mean * sum dzm)
+    m2 = is * (m2 - mu * m1);
     // ---- slab: every element written (zeros from idle waves), no atomics
     float* slab = a.slab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * slab_floats(p.K, NCT);
     const int ncp = NCT * 32;
@@ -373,39 +422,114 @@ __global__ __launch_bounds__(E_NT) void enc1_bwd_kernel(E1Bwd a) {
             }
         const float t1 = m1 + __shfl_xor(m1, 32, 64), t2 = m2 + __shfl_xor(m2, 32, 64);
         if (h == 0) {
-            slab[(size_t)2 * p.K * ncp + ncp + k] = t1;
-            slab[(size_t)2 * p.K * ncp + ncp + p.K + k] = t2;
+            slab[(size_t)2 * p.K * ncp + k] = t1;
+            slab[(size_t)2 * p.K * ncp + p.K + k] = t2;
         }
     }
-    // S: every row of accS holds the same sums; the workgroup of channel group 0 records them
-    if (wave < NCT && h == 0) slab[(size_t)2 * p.K * ncp + wave * 32 + r] = active ? accS[0] : 0.f;
+}
+
+// Sums of the input the patch sums S are made of: per 8-channel half, over all images, the sum of
+// every pixel (0), of the first / last row (1, 2), of the first / last column (3, 4) and of the
+// four corners (5: (0,0), 6: (0,W-1), 7: (H-1,0), 8: (H-1,W-1)).  One slab [9][16] per workgroup.
+__global__ __launch_bounds__(E_NT) void enc1_input_sums_kernel(const bf16* __restrict__ x, float* __restrict__ out, int N,
+                                                               int H, int W) {
+    __shared__ float red[9][16][E_NT / 64];
+    const int half = threadIdx.x & 1, pl = threadIdx.x >> 1;     // 128 pixels per pass
+    float acc[9][8];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+    const int rows = N * H;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int y = row % H;
+        const bool top = y == 0, bot = y == H - 1;
+        const bf16* xr = x + (size_t)row * W * 16 + half * 8;
+        for (int px = pl; px < W; px += E_NT / 2) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + (size_t)px * 16);
+            const bool left = px == 0, right = px == W - 1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                acc[0][e] += f;
+                acc[1][e] += top ? f : 0.f;
+                acc[2][e] += bot ? f : 0.f;
+                acc[3][e] += left ? f : 0.f;
+                acc[4][e] += right ? f : 0.f;
+                acc[5][e] += top && left ? f : 0.f;
+                acc[6][e] += top && right ? f : 0.f;
+                acc[7][e] += bot && left ? f : 0.f;
+                acc[8][e] += bot && right ? f : 0.f;
+            }
+        }
+    }
+    // lanes of equal parity hold the same channel half: reduce over 32 lanes, then over the waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[q][e];
+#pragma unroll
+            for (int o = 32; o >= 2; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane < 2) red[q][lane * 8 + e][wave] = v;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 16; i += E_NT) {
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < E_NT / 64; ++w2) v += red[i / 16][i % 16][w2];
+        out[(size_t)blockIdx.x * 144 + i] = v;
+    }
 }
 
 // dW[k][c][tap] = scale[k] * (A1 - m1/M * S - m2/M * invstd[k] * (A2 - mean[k] * S))   (training)
 //              = scale[k] * A1                                                          (eval)
-// dgamma = m2, dbeta = m1.  One thread per (k, column); slabs are added in index order.
-__global__ void enc1_bwd_finalize_kernel(const float* __restrict__ slabs, int nslabs, int ky /* slab groups per K */,
-                                         int K, int nct, int Creal, double inv_m, int training,
-                                         const float* __restrict__ scale, const float* __restrict__ mean,
-                                         const float* __restrict__ invstd, float* __restrict__ dw,
-                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// dgamma = m2, dbeta = m1.  32 lanes per (k, column): each adds every 32nd slab, then a shuffle
+// tree (fixed order: reproducible).  S[(tap, c)] = all - excluded border row - excluded border
+// column + their common corner (tap row 0 never reaches the last image row, tap row 2 never the
+// first; columns alike).
+constexpr int E_SUMS_GRID = 256;
+__global__ __launch_bounds__(256) void enc1_bwd_finalize_kernel(const float* __restrict__ slabs, int nslabs,
+                                                                const float* __restrict__ insums, int K, int nct,
+                                                                int Creal, double inv_m, int training,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ dw,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int ncp = nct * 32, ncols = 9 * Creal;
     const size_t sf_ = slab_floats(K, nct);
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= K * ncols) return;
-    const int k = idx / ncols, col = idx - k * ncols;
+    const int sub = threadIdx.x & 31;
+    const int idx = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = idx < K * ncols;
+    const int k = live ? idx / ncols : 0, col = live ? idx - k * ncols : 0;
     const int grp = k / 128;                 // the slab group (blockIdx.y) that owns this channel
-    double a1 = 0.0, a2 = 0.0, s = 0.0, m1 = 0.0, m2 = 0.0;
-    for (int i = 0; i < nslabs; ++i) {
+    const int tap = col / Creal, c = col - tap * Creal, ty = tap / 3, tx = tap % 3;
+    double a1 = 0.0, a2 = 0.0, m1 = 0.0, m2 = 0.0, s = 0.0;
+    for (int i = sub; i < nslabs; i += 32) {
         const float* sl = slabs + ((size_t)grp * nslabs + i) * sf_;
         a1 += (double)sl[(size_t)k * ncp + col];
         a2 += (double)sl[(size_t)(K + k) * ncp + col];
-        m1 += (double)sl[(size_t)2 * K * ncp + ncp + k];
-        m2 += (double)sl[(size_t)2 * K * ncp + ncp + K + k];
-        s += (double)slabs[(size_t)i * sf_ + (size_t)2 * K * ncp + col];   // group 0 holds S
+        m1 += (double)sl[(size_t)2 * K * ncp + k];
+        m2 += (double)sl[(size_t)2 * K * ncp + K + k];
     }
-    (void)ky;
-    const int tap = col / Creal, c = col - tap * Creal;
+    const int rowq = ty == 0 ? 2 : ty == 2 ? 1 : -1, colq = tx == 0 ? 4 : tx == 2 ? 3 : -1;
+    const int corq = (ty == 0 && tx == 0) ? 8 : (ty == 0 && tx == 2) ? 7 : (ty == 2 && tx == 0) ? 6 : (ty == 2 && tx == 2) ? 5 : -1;
+    for (int i = sub; i < E_SUMS_GRID; i += 32) {
+        const float* q = insums + (size_t)i * 144 + c;
+        double v = (double)q[0];
+        if (rowq >= 0) v -= (double)q[rowq * 16];
+        if (colq >= 0) v -= (double)q[colq * 16];
+        if (corq >= 0) v += (double)q[corq * 16];
+        s += v;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
+        m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64);
+        s += __shfl_xor(s, o, 64);
+    }
+    if (!live || sub != 0) return;
     double g = a1;
     if (training) g = a1 - m1 * inv_m * s - m2 * inv_m * (double)invstd[k] * (a2 - (double)mean[k] * s);
     dw[((size_t)k * Creal + c) * 9 + tap] = (float)((double)scale[k] * g);
@@ -472,7 +596,7 @@ extern "C" size_t sf_enc1_bwd_workspace_bytes(int N, int H, int W, int K, int Cr
     const int nct = (9 * Creal + 31) / 32;
     const long long ntiles = (long long)N * ((W + E_TW - 1) / E_TW) * ((H + E_TH - 1) / E_TH);
     const long long gx = ntiles < 512 ? ntiles : 512;
-    return sizeof(float) * slab_floats(K, nct) * (size_t)gx * (size_t)((K + 127) / 128);
+    return sizeof(float) * (slab_floats(K, nct) * (size_t)gx * (size_t)((K + 127) / 128) + (size_t)E_SUMS_GRID * 144);
 }
 
 extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const float* scale, const float* shift,
@@ -490,16 +614,19 @@ extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const f
     a.Creal = Creal; a.ncols = 9 * Creal;
     const int nct = (a.ncols + 31) / 32;
     const int gx = a.c.ntiles < 512 ? a.c.ntiles : 512, gy = (K + 127) / 128;
+    float* insums = ws + slab_floats(K, nct) * (size_t)gx * (size_t)gy;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)E_PP * E_ROWB;
-    switch (nct) {
-        case 1: hipLaunchKernelGGL(enc1_bwd_kernel<1>, dim3(gx, gy), dim3(E_NT), lds, s, a); break;
-        case 2: hipLaunchKernelGGL(enc1_bwd_kernel<2>, dim3(gx, gy), dim3(E_NT), lds, s, a); break;
-        case 3: hipLaunchKernelGGL(enc1_bwd_kernel<3>, dim3(gx, gy), dim3(E_NT), lds, s, a); break;
-        default: hipLaunchKernelGGL(enc1_bwd_kernel<4>, dim3(gx, gy), dim3(E_NT), lds, s, a); break;
+    const size_t lds = (size_t)E_PP * E_ROWB + (size_t)9 * 128 * E_ROWB + (size_t)E_DCH * 16;
+    void (*kern)(E1Bwd) = nct == 1 ? enc1_bwd_kernel<1> : nct == 2 ? enc1_bwd_kernel<2> : nct == 3 ? enc1_bwd_kernel<3> : enc1_bwd_kernel<4>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        sf_set_error("sf_enc1_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
+        return SF_ELAUNCH;
     }
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(E_NT), lds, s, a);
+    hipLaunchKernelGGL(enc1_input_sums_kernel, dim3(E_SUMS_GRID), dim3(E_NT), 0, s, (const bf16*)x, insums, N, H, W);
     const int total = K * a.ncols;
-    hipLaunchKernelGGL(enc1_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ws, gx, gy, K, nct, Creal,
+    hipLaunchKernelGGL(enc1_bwd_finalize_kernel, dim3((total + 7) / 8), dim3(256), 0, s, ws, gx, insums, K, nct, Creal,
                        1.0 / ((double)N * H * W), training, scale, mean, invstd, dw, dgamma, dbeta);
     SF_LAUNCH_CHECK("sf_enc1_bwd");
     return SF_OK;
