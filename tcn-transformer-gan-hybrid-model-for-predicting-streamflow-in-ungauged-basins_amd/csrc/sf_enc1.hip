@@ -73,7 +73,9 @@ __device__ __forceinline__ void stage_weights(const E1Params& p, char* sW) {
         const int half = i & 1, row = i >> 1;        // row = k * 9 + tap in the packed tensor
         const int k = row / 9, tap = row - k * 9;
         const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w) + (size_t)i * 16);
-        *reinterpret_cast<uint4*>(sW + ((tap * p.K + k) * 2 + half) * 16) = v;
+        // the two 16-byte halves of a row are swapped on every second group of 8 rows: 16 lanes
+        // reading 16 consecutive rows then cover all 64 banks once
+        *reinterpret_cast<uint4*>(sW + ((tap * p.K + k) * 2 + (half ^ ((k >> 3) & 1))) * 16) = v;
     }
 }
 
@@ -93,11 +95,16 @@ __device__ __forceinline__ void load_patch(const E1Params& p, __amdgpu_buffer_rs
         regs[j] = *reinterpret_cast<const uint4*>(&v);
     }
 }
+// SWZ: the halves of a patch row are swapped on odd patch lines, which separates the two lanes of
+// a 16-lane read group that sit one line apart (the 2x2 window ordering of the MFMA rows)
+template <bool SWZ>
 __device__ __forceinline__ void store_patch(char* sP, const uint4* regs) {
 #pragma unroll
     for (int j = 0; j < E_PLOADS; ++j) {
         const int c = threadIdx.x + j * E_NT;
-        if (c < E_PCHUNKS) *reinterpret_cast<uint4*>(sP + c * 16) = regs[j];
+        const int row = c >> 1, py = row / E_PW;
+        const int cs = SWZ ? (c ^ (py & 1)) : c;
+        if (c < E_PCHUNKS) *reinterpret_cast<uint4*>(sP + cs * 16) = regs[j];
     }
 }
 
@@ -114,8 +121,10 @@ __global__ __launch_bounds__(E_NT, 3) void enc1_kernel(E1Params p) {
 
     // lane constants.  MFMA row r of a row tile = window r >> 2 (along x), position r & 3 in it.
     const int a_px = 2 * (r >> 2) + (r & 1), a_py = (r >> 1) & 1;
-    const int a_off = (a_py * E_PW + a_px) * E_ROWB + 16 * h;     // + (2 rt + ty) * PW * 32 + tx * 32
-    const int b_off = r * E_ROWB + 16 * h;                        // + (tap * K + kt * 32) * 32
+    // + (2 rt + ty) * PW * 32 + tx * 32; the half depends on the parity of the patch line a_py + ty
+    const int a_off0 = (a_py * E_PW + a_px) * E_ROWB + 16 * (h ^ a_py);
+    const int a_off1 = (a_py * E_PW + a_px) * E_ROWB + 16 * (h ^ a_py ^ 1);
+    const int b_off = r * E_ROWB + 16 * (h ^ ((r >> 3) & 1));     // + (tap * K + kt * 32) * 32
 
     float ssum[NKT], ssq[NKT], sc[NKT], sf[NKT];
 #pragma unroll
@@ -131,19 +140,20 @@ __global__ __launch_bounds__(E_NT, 3) void enc1_kernel(E1Params p) {
     load_patch(p, rs, tp, t < p.ntiles, pre);
     for (; t < p.ntiles; t += gridDim.x) {
         __syncthreads();                 // everyone is done with the previous patch (and sW is staged)
-        store_patch(sP, pre);
+        store_patch<true>(sP, pre);
         __syncthreads();
         const TilePos cur = tp;
         const int tn = t + gridDim.x;
         tp = tile_pos(p, tn < p.ntiles ? tn : 0);
         load_patch(p, rs, tp, tn < p.ntiles, pre);   // next tile's patch flies under this tile's MFMAs
+        const bool full = cur.y0 + E_TH <= p.H && cur.x0 + E_TW <= p.W;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int rt = wave * 2 + q;             // window row of the tile
             bf16x8 fa[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
-                fa[tap] = *reinterpret_cast<const bf16x8*>(sP + a_off + ((2 * rt + tap / 3) * E_PW + tap % 3) * E_ROWB);
+                fa[tap] = *reinterpret_cast<const bf16x8*>(sP + (tap / 3 == 1 ? a_off1 : a_off0) + ((2 * rt + tap / 3) * E_PW + tap % 3) * E_ROWB);
             // validity of the lane's 16 pixels: register i -> window 2 (i >> 2) + h, position i & 3
             const int gy0 = cur.y0 + 2 * rt;
 #pragma unroll
@@ -158,32 +168,40 @@ __global__ __launch_bounds__(E_NT, 3) void enc1_kernel(E1Params p) {
                     const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + b_off + (tap * p.K + kt * 32) * E_ROWB);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap], fb, acc, 0, 0, 0);
                 }
+                // tiles inside the image skip the validity tests (wave-uniform branch)
                 if (MODE == E_STATS) {
                     float s = 0.f, q2 = 0.f;
+                    if (full) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int gy = gy0 + ((i >> 1) & 1), gx = cur.x0 + 2 * (2 * (i >> 2) + h) + (i & 1);
-                        const float z = (float)(bf16)acc[i];
-                        const bool ok = gy < p.H && gx < p.W;
-                        s += ok ? z : 0.f;
-                        q2 += ok ? z * z : 0.f;
+                        for (int i = 0; i < 16; i += 2) {
+                            const unsigned pk = pack_bf16x2(acc[i], acc[i + 1]);
+                            const float z0 = __uint_as_float(pk << 16), z1 = __uint_as_float(pk & 0xffff0000u);
+                            s += z0 + z1;
+                            q2 += z0 * z0 + z1 * z1;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int gy = gy0 + ((i >> 1) & 1), gx = cur.x0 + 2 * (2 * (i >> 2) + h) + (i & 1);
+                            const float z = (float)(bf16)acc[i];
+                            const bool ok = gy < p.H && gx < p.W;
+                            s += ok ? z : 0.f;
+                            q2 += ok ? z * z : 0.f;
+                        }
                     }
                     ssum[kt] += s;
                     ssq[kt] += q2;
                 } else {
                     const int wy = (cur.y0 >> 1) + rt;
+                    bf16* yrow = p.y + (((size_t)cur.n * PH + wy) * PWd + (cur.x0 >> 1) + h) * p.K + kt * 32 + r;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        float mx = 0.f;                       // max with 0 == ReLU, then max
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float z = (float)(bf16)acc[4 * g + e];
-                            const float v = z * sc[kt] + sf[kt];
-                            mx = v > mx ? v : mx;
-                        }
+                        const unsigned p01 = pack_bf16x2(acc[4 * g], acc[4 * g + 1]), p23 = pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]);
+                        const float v0 = __uint_as_float(p01 << 16) * sc[kt] + sf[kt], v1 = __uint_as_float(p01 & 0xffff0000u) * sc[kt] + sf[kt];
+                        const float v2 = __uint_as_float(p23 << 16) * sc[kt] + sf[kt], v3 = __uint_as_float(p23 & 0xffff0000u) * sc[kt] + sf[kt];
+                        const float mx = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), 0.f);   // ReLU, then max
                         const int wx = (cur.x0 >> 1) + 2 * g + h;
-                        if (wy < PH && wx < PWd)
-                            p.y[(((size_t)cur.n * PH + wy) * PWd + wx) * p.K + kt * 32 + r] = (bf16)mx;
+                        if (full || (wy < PH && wx < PWd)) yrow[(size_t)2 * g * p.K] = (bf16)mx;
                     }
                 }
             }
@@ -278,9 +296,9 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd_kernel(E1Bwd a) {
         const int kg = blockIdx.y * 128 + kk;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (kg < p.K) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.w) + ((size_t)kg * 9 + tap) * 32 + half * 16);
-        *reinterpret_cast<uint4*>(sWb + ((tap * 128 + kk) * 2 + half) * 16) = v;
+        *reinterpret_cast<uint4*>(sWb + ((tap * 128 + kk) * 2 + (half ^ ((kk >> 3) & 1))) * 16) = v;
     }
-    const int w_off = (wave * 32 + r) * E_ROWB + 16 * h;   // + tap * 128 * 32
+    const int w_off = (wave * 32 + r) * E_ROWB + 16 * (h ^ ((r >> 3) & 1));   // + tap * 128 * 32 (halves swizzled)
     const float sc = p.scale[k], sf = p.shift[k], mu = a.mean[k], is = a.invstd[k];
 
     const int a_px = 2 * (r >> 2) + (r & 1), a_py = (r >> 1) & 1;
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd_kernel(E1Bwd a) {
     load_dyt(tp, t < p.ntiles, pred);
     for (; t < p.ntiles; t += gridDim.x) {
         __syncthreads();
-        store_patch(sP, pre);
+        store_patch<false>(sP, pre);
 #pragma unroll
         for (int j = 0; j < E_DLOADS; ++j) *reinterpret_cast<uint4*>(sD + (threadIdx.x + j * E_NT) * 16) = pred[j];
         __syncthreads();
@@ -441,25 +459,37 @@ __global__ __launch_bounds__(E_NT) void enc1_input_sums_kernel(const bf16* __res
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
     const int rows = N * H;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int y = row % H;
-        const bool top = y == 0, bot = y == H - 1;
-        const bf16* xr = x + (size_t)row * W * 16 + half * 8;
+    constexpr int RU = 4;                            // rows per trip, all loads issued first
+    for (int row0 = blockIdx.x * RU; row0 < rows; row0 += gridDim.x * RU) {
         for (int px = pl; px < W; px += E_NT / 2) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + (size_t)px * 16);
+            bf16x8 v[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int row = row0 + u < rows ? row0 + u : rows - 1;
+                v[u] = *reinterpret_cast<const bf16x8*>(x + ((size_t)row * W + px) * 16 + half * 8);
+            }
             const bool left = px == 0, right = px == W - 1;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = (float)v[e];
-                acc[0][e] += f;
-                acc[1][e] += top ? f : 0.f;
-                acc[2][e] += bot ? f : 0.f;
-                acc[3][e] += left ? f : 0.f;
-                acc[4][e] += right ? f : 0.f;
-                acc[5][e] += top && left ? f : 0.f;
-                acc[6][e] += top && right ? f : 0.f;
-                acc[7][e] += bot && left ? f : 0.f;
-                acc[8][e] += bot && right ? f : 0.f;
+            for (int u = 0; u < RU; ++u) {
+                if (row0 + u >= rows) break;
+                const int y = (row0 + u) % H;
+                const bool top = y == 0, bot = y == H - 1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[0][e] += (float)v[u][e];
+                if (top || bot || left || right) {       // 2 % of the pixels
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[u][e];
+                        acc[1][e] += top ? f : 0.f;
+                        acc[2][e] += bot ? f : 0.f;
+                        acc[3][e] += left ? f : 0.f;
+                        acc[4][e] += right ? f : 0.f;
+                        acc[5][e] += top && left ? f : 0.f;
+                        acc[6][e] += top && right ? f : 0.f;
+                        acc[7][e] += bot && left ? f : 0.f;
+                        acc[8][e] += bot && right ? f : 0.f;
+                    }
+                }
             }
         }
     }
@@ -485,51 +515,73 @@ __global__ __launch_bounds__(E_NT) void enc1_input_sums_kernel(const bf16* __res
 
 // dW[k][c][tap] = scale[k] * (A1 - m1/M * S - m2/M * invstd[k] * (A2 - mean[k] * S))   (training)
 //              = scale[k] * A1                                                          (eval)
-// dgamma = m2, dbeta = m1.  32 lanes per (k, column): each adds every 32nd slab, then a shuffle
-// tree (fixed order: reproducible).  S[(tap, c)] = all - excluded border row - excluded border
+// dgamma = m2, dbeta = m1.  Slabs are added in a fixed order (reproducible).  S[(tap, c)] = all - excluded border row - excluded border
 // column + their common corner (tap row 0 never reaches the last image row, tap row 2 never the
 // first; columns alike).
-constexpr int E_SUMS_GRID = 256;
-__global__ __launch_bounds__(256) void enc1_bwd_finalize_kernel(const float* __restrict__ slabs, int nslabs,
+constexpr int E_SUMS_GRID = 1024;
+__global__ __launch_bounds__(1024) void enc1_bwd_finalize_kernel(const float* __restrict__ slabs, int nslabs,
                                                                 const float* __restrict__ insums, int K, int nct,
                                                                 int Creal, double inv_m, int training,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, float* __restrict__ dw,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    // one workgroup per channel k; thread = (column, one of 8 slab parts): coalesced slab rows
+    constexpr int PARTS = 8;
+    __shared__ double sh[PARTS][5][128];
     const int ncp = nct * 32, ncols = 9 * Creal;
     const size_t sf_ = slab_floats(K, nct);
-    const int sub = threadIdx.x & 31;
-    const int idx = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const bool live = idx < K * ncols;
-    const int k = live ? idx / ncols : 0, col = live ? idx - k * ncols : 0;
+    const int k = blockIdx.x, col = threadIdx.x & 127, part = threadIdx.x >> 7;
     const int grp = k / 128;                 // the slab group (blockIdx.y) that owns this channel
-    const int tap = col / Creal, c = col - tap * Creal, ty = tap / 3, tx = tap % 3;
+    const bool live = col < ncols;
+    const int cc = live ? col : 0;
+    const int tap = cc / Creal, c = cc - tap * Creal, ty = tap / 3, tx = tap % 3;
     double a1 = 0.0, a2 = 0.0, m1 = 0.0, m2 = 0.0, s = 0.0;
-    for (int i = sub; i < nslabs; i += 32) {
-        const float* sl = slabs + ((size_t)grp * nslabs + i) * sf_;
-        a1 += (double)sl[(size_t)k * ncp + col];
-        a2 += (double)sl[(size_t)(K + k) * ncp + col];
-        m1 += (double)sl[(size_t)2 * K * ncp + k];
-        m2 += (double)sl[(size_t)2 * K * ncp + K + k];
-    }
-    const int rowq = ty == 0 ? 2 : ty == 2 ? 1 : -1, colq = tx == 0 ? 4 : tx == 2 ? 3 : -1;
-    const int corq = (ty == 0 && tx == 0) ? 8 : (ty == 0 && tx == 2) ? 7 : (ty == 2 && tx == 0) ? 6 : (ty == 2 && tx == 2) ? 5 : -1;
-    for (int i = sub; i < E_SUMS_GRID; i += 32) {
-        const float* q = insums + (size_t)i * 144 + c;
-        double v = (double)q[0];
-        if (rowq >= 0) v -= (double)q[rowq * 16];
-        if (colq >= 0) v -= (double)q[colq * 16];
-        if (corq >= 0) v += (double)q[corq * 16];
-        s += v;
-    }
+    const float* base = slabs + (size_t)grp * nslabs * sf_;
+    // batches of 8 slabs: all loads of a batch are issued before the first add
+    for (int i0 = part; i0 < nslabs; i0 += PARTS * 8) {
+        float v1[8], v2[8], v3[8], v4[8];
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-        a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
-        m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64);
-        s += __shfl_xor(s, o, 64);
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * PARTS;
+            const float* sl = base + (size_t)(i < nslabs ? i : i0) * sf_;
+            v1[u] = sl[(size_t)k * ncp + cc];
+            v2[u] = sl[(size_t)(K + k) * ncp + cc];
+            v3[u] = sl[(size_t)2 * K * ncp + k];
+            v4[u] = sl[(size_t)2 * K * ncp + K + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = i0 + u * PARTS < nslabs;
+            a1 += ok ? (double)v1[u] : 0.0;
+            a2 += ok ? (double)v2[u] : 0.0;
+            m1 += ok ? (double)v3[u] : 0.0;
+            m2 += ok ? (double)v4[u] : 0.0;
+        }
     }
-    if (!live || sub != 0) return;
+    // S: the excluded row / column / corner enter with a 0 / 1 factor (unconditional loads)
+    const int rowq = ty == 0 ? 2 : 1, colq = tx == 0 ? 4 : 3;
+    const int corq = ty == 0 ? (tx == 0 ? 8 : 7) : (tx == 0 ? 6 : 5);
+    const double fr = ty != 1 ? 1.0 : 0.0, fc = tx != 1 ? 1.0 : 0.0, fk = (ty != 1 && tx != 1) ? 1.0 : 0.0;
+    for (int i0 = part; i0 < E_SUMS_GRID; i0 += PARTS * 4) {
+        float q0[4], q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PARTS;
+            const float* q = insums + (size_t)(i < E_SUMS_GRID ? i : i0) * 144 + c;
+            q0[u] = q[0]; q1[u] = q[rowq * 16]; q2[u] = q[colq * 16]; q3[u] = q[corq * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * PARTS < E_SUMS_GRID) s += (double)q0[u] - fr * (double)q1[u] - fc * (double)q2[u] + fk * (double)q3[u];
+    }
+    sh[part][0][col] = a1; sh[part][1][col] = a2; sh[part][2][col] = m1; sh[part][3][col] = m2; sh[part][4][col] = s;
+    __syncthreads();
+    if (part != 0 || !live) return;
+#pragma unroll
+    for (int q = 1; q < PARTS; ++q) {
+        a1 += sh[q][0][col]; a2 += sh[q][1][col]; m1 += sh[q][2][col]; m2 += sh[q][3][col]; s += sh[q][4][col];
+    }
     double g = a1;
     if (training) g = a1 - m1 * inv_m * s - m2 * inv_m * (double)invstd[k] * (a2 - (double)mean[k] * s);
     dw[((size_t)k * Creal + c) * 9 + tap] = (float)((double)scale[k] * g);
@@ -626,7 +678,8 @@ extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const f
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(E_NT), lds, s, a);
     hipLaunchKernelGGL(enc1_input_sums_kernel, dim3(E_SUMS_GRID), dim3(E_NT), 0, s, (const bf16*)x, insums, N, H, W);
     const int total = K * a.ncols;
-    hipLaunchKernelGGL(enc1_bwd_finalize_kernel, dim3((total + 7) / 8), dim3(256), 0, s, ws, gx, insums, K, nct, Creal,
+    (void)total;
+    hipLaunchKernelGGL(enc1_bwd_finalize_kernel, dim3(K), dim3(1024), 0, s, ws, gx, insums, K, nct, Creal,
                        1.0 / ((double)N * H * W), training, scale, mean, invstd, dw, dgamma, dbeta);
     SF_LAUNCH_CHECK("sf_enc1_bwd");
     return SF_OK;
