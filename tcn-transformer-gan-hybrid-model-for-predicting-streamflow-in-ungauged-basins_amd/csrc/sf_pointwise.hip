@@ -55,6 +55,68 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
     }
 }
 
+// Few channels (Cpad <= 16, bf16): a thread converts 4 consecutive pixels -- one float4 load per
+// channel (a wave reads 1 KB runs of each channel plane), 4 x Cpad contiguous bf16 out.
+template <int CP>
+__global__ __launch_bounds__(NT) void nchw_to_nhwc_px4_kernel(const float* __restrict__ in, bf16* __restrict__ out,
+                                                              unsigned nquads, int C, unsigned HW) {
+    const unsigned q = blockIdx.x * NT + threadIdx.x;
+    if (q >= nquads) return;
+    const unsigned pix = q * 4, n = pix / HW, hw = pix - n * HW;
+    const float* src = in + (size_t)n * C * HW + hw;
+    float4 v[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) v[c] = *reinterpret_cast<const float4*>(src + (size_t)(c < C ? c : 0) * HW);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c0 = 0; c0 < CP; c0 += 8) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = c0 + e < C ? (&v[c0 + e].x)[k] : 0.f;
+            store_chunk<bf16>(out + ((size_t)pix + k) * CP + c0, f);
+        }
+    }
+}
+
+// Many channels: a workgroup transposes a tile of 64 pixels x 64 channels through LDS, so that
+// both the channel-plane reads (256-byte runs) and the pixel-row writes (128-byte runs) coalesce.
+template <typename T>
+__global__ __launch_bounds__(NT) void nchw_to_nhwc_tile_kernel(const float* __restrict__ in, T* __restrict__ out, int C,
+                                                               int HW, int Cpad, int ptiles, int ctiles) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    __shared__ float sm[64][65];
+    const int ct = blockIdx.x % ctiles, rest = blockIdx.x / ctiles;
+    const int pt = rest % ptiles, n = rest / ptiles;
+    const int c0 = ct * 64, p0 = pt * 64;
+    {
+        const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;
+        const bool pok = p0 + px < HW;
+        const float* src = in + ((size_t)n * C + c0) * HW + p0 + (pok ? px : 0);
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = cq * 16 + i;
+            v[i] = src[(size_t)(c0 + ch < C ? ch : 0) * HW];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = cq * 16 + i;
+            sm[ch][px] = (pok && c0 + ch < C) ? v[i] : 0.f;
+        }
+    }
+    __syncthreads();
+    constexpr int CHUNKS = 64 / EPC;            // chunks per pixel row of the tile
+    for (int i = threadIdx.x; i < 64 * CHUNKS; i += NT) {
+        const int chunk = i % CHUNKS, px = i / CHUNKS;
+        if (p0 + px >= HW || c0 + chunk * EPC >= Cpad) continue;
+        float f[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = sm[chunk * EPC + e][px];
+        store_chunk<T>(out + ((size_t)n * HW + p0 + px) * Cpad + c0 + chunk * EPC, f);
+    }
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, long long total, int C,
                                     int HW, int Cpad) {
@@ -394,6 +456,29 @@ extern "C" int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int
     SF_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "sf_nchw_to_nhwc: bad arguments");
     SF_REQUIRE(Cpad % (dtype == SF_BF16 ? 8 : 4) == 0, "sf_nchw_to_nhwc: Cpad=%d not a chunk multiple", Cpad);
     const long long npix = (long long)N * H * W;
+    const int HWi = H * W;
+    if (dtype == SF_BF16 && (Cpad == 8 || Cpad == 16) && HWi % 4 == 0 && npix < 0x7fffffffLL && ((uintptr_t)in & 15) == 0) {
+        const unsigned nquads = (unsigned)(npix / 4);
+        const unsigned grid = (nquads + NT - 1) / NT;
+        if (Cpad == 8)
+            hipLaunchKernelGGL(nchw_to_nhwc_px4_kernel<8>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
+                               nquads, C, (unsigned)HWi);
+        else
+            hipLaunchKernelGGL(nchw_to_nhwc_px4_kernel<16>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
+                               nquads, C, (unsigned)HWi);
+        SF_LAUNCH_CHECK("sf_nchw_to_nhwc");
+        return SF_OK;
+    }
+    if (Cpad >= 64) {
+        const int ptiles = (HWi + 63) / 64, ctiles = (Cpad + 63) / 64;
+        const long long blocks = (long long)N * ptiles * ctiles;
+        if (blocks < 0x7fffffffLL) {
+            DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_tile_kernel<T>, dim3((unsigned)blocks), dim3(NT), 0,
+                                                 (hipStream_t)stream, in, (T*)out, C, HWi, Cpad, ptiles, ctiles));
+            SF_LAUNCH_CHECK("sf_nchw_to_nhwc");
+            return SF_OK;
+        }
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(npix)), dim3(NT), 0,
                                          (hipStream_t)stream, in, (T*)out, npix, C, H * W, Cpad));
     SF_LAUNCH_CHECK("sf_nchw_to_nhwc");
