@@ -30,17 +30,18 @@ __device__ __forceinline__ float drop_mask(float p, unsigned long long seed, int
 }
 
 // acc[t] = wrow . v[t] for the T tokens (v in LDS, row stride ldv): the weight row is read once,
-// four 16-byte loads in flight
+// sixteen 16-byte loads in flight
 __device__ __forceinline__ void dot_row_tokens(const float* __restrict__ wrow, const float* __restrict__ v, int ldv,
                                                int n, int T, float* acc) {
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
-    for (int d = 0; d < n; d += 16) {
-        float4 w[4];
+    constexpr int NL = 16;   // 16-byte loads in flight per thread (the kernel is latency bound)
+    for (int d = 0; d < n; d += 4 * NL) {
+        float4 w[NL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = *reinterpret_cast<const float4*>(wrow + (d + 4 * k < n ? d + 4 * k : 0));
+        for (int k = 0; k < NL; ++k) w[k] = *reinterpret_cast<const float4*>(wrow + (d + 4 * k < n ? d + 4 * k : 0));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NL; ++k) {
             if (d + 4 * k < n) {
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t)
@@ -257,15 +258,16 @@ __device__ __forceinline__ void tok_matmul(const float* __restrict__ in, int ldi
         if (live) {
             const int o0 = part * per, o1 = o0 + per < NO ? o0 + per : NO;
             const float* wp = Wm + 4 * j4;
-            for (int ob = o0; ob < o1; ob += 8) {
-                float4 w[8];
+            constexpr int NL = 8;    // more in flight measured slower here (fewer, longer dependent add chains win)
+            for (int ob = o0; ob < o1; ob += NL) {
+                float4 w[NL];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < NL; ++k) {
                     const int o = ob + k < o1 ? ob + k : o0;
                     w[k] = *reinterpret_cast<const float4*>(wp + (size_t)o * ldw);
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < NL; ++k) {
                     if (ob + k < o1) {
 #pragma unroll
                         for (int t = 0; t < MAXT; ++t)
