@@ -110,7 +110,7 @@ def main():
     # HIP-event pairs cost GPU time, so inside the timed region only the launches of the dominant
     # kernel are bracketed (3 per step); the other two MFMA kernels are timed in extra steps after it
     dom = "conv3_dma_wide_kernel"
-    other_tags = ("conv3_dma_kernel", "wgrad3_dma_kernel")
+    other_tags = ("conv3_dma_res_kernel", "conv3_dma_kernel", "wgrad3_dma_kernel")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -141,13 +141,15 @@ def main():
     if rank == 0:
         # The three MFMA kernels of the 3x3 convolutions, every launch timed with HIP events on the
         # launch stream; algorithmic flops of a launch = 2 * N*H*W * Cin * Cout * 9 with the real
-        # channel counts.  conv3_dma_wide_kernel / conv3_dma_kernel are the two shapes of the
-        # persistent forward / data-gradient kernel, wgrad3_dma_kernel the weight gradient (its
+        # channel counts.  conv3_dma_wide_kernel / conv3_dma_kernel / conv3_dma_res_kernel are the
+        # shapes of the persistent forward / data-gradient kernel (res: weights resident in LDS), wgrad3_dma_kernel the weight gradient (its
         # event pair also spans the small slab-reduction launch that follows it).
         n_l, ms_l, achieved = dom_stats
         others = {}
         for t in other_tags:
             n_o, ms_o, tf_o = ops.timed_tflops(t)
+            if n_o == 0:
+                continue
             others[t] = {"launches": n_o, "ms_per_launch": round(ms_o, 4), "TFLOP/s": round(tf_o, 2),
                          "measured": "3 extra steps after the timed region"}
         out = {

@@ -267,7 +267,10 @@ struct ItemPos {
     int n, y0, x0, k0;     // decoded item
 };
 
-template <int KT, int CK>
+// RES (C == 2 stages, K <= KT): the weights of both stages are copied once and stay in LDS for
+// the whole kernel -- [stage 0 weights][stage 1 weights][patch buffer 0][patch buffer 1], the
+// same 152 KB -- so an item fetches its two patch stages only: half the bytes per MFMA.
+template <int KT, int CK, bool RES>
 __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     using Cf = DCfg<KT, CK>;
     constexpr int ROWB = Cf::ROWB, SLOTS = Cf::SLOTS, RPP = Cf::RPP, MT = Cf::MT, KS = Cf::KS, NPOS = Cf::NPOS;
@@ -342,18 +345,22 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         return ss;
     };
     // piece j of a stage's copy: j < D_NWJ weights, then the patch
+    auto issue_wpiece = [&](const StageSrc& ss, char* dst, int j) {
+        const int job = wave + 8 * j;
+        if (D_WJOBS % 8 == 0 || job < D_WJOBS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(dst + job * 1024), 16, w_rel[j], 0, 0, 0);
+    };
+    constexpr int P_OFF = RES ? 0 : D_WIMG;      // patch image inside a stage buffer
     auto issue_piece = [&](const StageSrc& ss, char* buf, int j) {
         if (j < D_NWJ) {
-            const int job = wave + 8 * j;
-            if (D_WJOBS % 8 == 0 || job < D_WJOBS)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(buf + job * 1024), 16, w_rel[j], 0, 0, 0);
+            if (!RES) issue_wpiece(ss, buf, j);
         } else {
             const int i = j - D_NWJ, job = wave + 8 * i;
             if (D_PJOBS % 8 == 0 || job < D_PJOBS) {
                 const int gy = ss.ym1 + (p_pyx[i] >> 16), gx = ss.xm1 + (p_pyx[i] & 0xffff);
                 const bool ok = p_pyx[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
                 const int voff = ok ? ss.ioff + p_rel[i] : (int)0x80000000;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.irs, (lptr_t)(buf + D_WIMG + job * 1024), 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.irs, (lptr_t)(buf + P_OFF + job * 1024), 16, voff, 0, 0, 0);
             }
         }
     };
@@ -400,10 +407,11 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // before the 2 MT MFMAs of position i (pinned order, counted lgkmcnt).
     // One copy piece of the next stage is issued per position (an LDS-DMA instruction holds the
     // issuing wave for ~100 cycles; spread out, the other wave's MFMAs cover it).
-    auto run_stage = [&](const char* __restrict__ cur, char* __restrict__ fill, const StageSrc& ss) {
-        const char* wl0 = cur + aLane0;
-        const char* wl1 = cur + aLane1;
-        const char* pl = cur + D_WIMG;
+    auto run_stage = [&](const char* __restrict__ cur, char* __restrict__ fill, const StageSrc& ss,
+                         const char* __restrict__ wts) {
+        const char* wl0 = wts + aLane0;
+        const char* wl1 = wts + aLane1;
+        const char* pl = cur + P_OFF;
         bf16x8 fa[2][MT], fb[2][2];
         auto issue = [&](int i) {
             const int t = i / KS, ks = i % KS, s = i & 1;
@@ -561,10 +569,19 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     cur.q = jblk; cur.chunk = 0;
     if (cur.q >= nitems) return;
     decode(cur);
+    char* const buf0 = RES ? smd + 2 * D_WIMG : smd;
+    char* const buf1 = buf0 + (RES ? Cf::PIMG : D_BUF);
+    if (RES) {   // both weight stages, once
+        ItemPos w1 = cur;
+        w1.chunk = 1;
+        const StageSrc s0 = stage_src(cur, true), s1 = stage_src(w1, true);
+#pragma unroll
+        for (int j = 0; j < D_NWJ; ++j) { issue_wpiece(s0, smd, j); issue_wpiece(s1, smd + D_WIMG, j); }
+    }
     {
         const StageSrc ss = stage_src(cur, true);
 #pragma unroll
-        for (int j = 0; j < D_NWJ + D_NPJ; ++j) issue_piece(ss, smd, j);
+        for (int j = 0; j < D_NWJ + D_NPJ; ++j) issue_piece(ss, buf0, j);
     }
     nxt = cur;
     auto advance = [&](ItemPos& it) {
@@ -578,7 +595,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // one step of the pipeline; `cur_buf` holds the landed stage, `fill` takes the next copy
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
         const StageSrc ss = stage_src(nxt, nxt.q < nitems);
-        run_stage(cur_buf, fill, ss);
+        run_stage(cur_buf, fill, ss, RES ? smd + cur.chunk * D_WIMG : cur_buf);
         if (cur.chunk == p.nchunks - 1) {
             epilogue(cur);
             zero_acc();
@@ -590,18 +607,19 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         // the stage's copy has landed (own vmcnt, then the barrier) and every wave is done
         // reading the buffer the next copy goes to
         __syncthreads();
-        step(smd, smd + D_BUF);
+        step(buf0, buf1);
         if (cur.q >= nitems) break;
         __syncthreads();
-        step(smd + D_BUF, smd);
+        step(buf1, buf0);
         if (cur.q >= nitems) break;
     }
 }
 
 // (plain kernels around the templated body: hipcc does not emit the host stub of a kernel
 // template whose body holds these buffer-resource lambdas)
-__global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) { conv3_dma_body<64, 32>(p); }
-__global__ __launch_bounds__(D_NT, 2) void conv3_dma_wide_kernel(C3DParams p) { conv3_dma_body<128, 16>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) { conv3_dma_body<64, 32, false>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_res_kernel(C3DParams p) { conv3_dma_body<64, 32, true>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_wide_kernel(C3DParams p) { conv3_dma_body<128, 16, false>(p); }
 
 // tile of the persistent kernel: at most D_TP pixels, patch at most D_PP; fewest tiles, least halo
 void pick_tile_dma(int H, int W, int* th, int* tw) {
@@ -619,7 +637,7 @@ void pick_tile_dma(int H, int W, int* th, int* tw) {
     *th = bth; *tw = btw;
 }
 
-template <int KT, int CK> int launch3_dma(const C3Params& q, hipStream_t s) {
+template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, hipStream_t s) {
     using Cf = DCfg<KT, CK>;
     C3DParams p;
     p.in = q.in; p.w = q.w; p.bias = q.bias; p.aux = q.aux; p.out = q.out;
@@ -639,9 +657,10 @@ template <int KT, int CK> int launch3_dma(const C3Params& q, hipStream_t s) {
     p.ktiles = (p.K + KT - 1) / KT;
     p.nchunks = (p.C + CK - 1) / CK;
     const size_t lds = 2 * (size_t)Cf::BUF + sizeof(float) * D_BIAS_MAX;
+    void (*kern)(C3DParams) = RES ? &conv3_dma_res_kernel : KT == 64 ? &conv3_dma_kernel : &conv3_dma_wide_kernel;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(KT == 64 ? &conv3_dma_kernel : &conv3_dma_wide_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("sf_conv3x3: cannot raise the dynamic LDS limit to %zu bytes", lds);
             return SF_ELAUNCH;
@@ -651,8 +670,7 @@ template <int KT, int CK> int launch3_dma(const C3Params& q, hipStream_t s) {
     long long items = ntiles * p.ktiles;
     long long grid = (items + 7) / 8 * 8;
     if (grid > 256) grid = 256;
-    if (KT == 64) hipLaunchKernelGGL(conv3_dma_kernel, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
-    else hipLaunchKernelGGL(conv3_dma_wide_kernel, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
     SF_LAUNCH_CHECK("sf_conv3x3");
     return SF_OK;
 }
@@ -716,6 +734,7 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
     p.tiles_y = (H + p.TH - 1) / p.TH;
     hipStream_t s = (hipStream_t)stream;
     if (K <= D_BIAS_MAX && C % 16 == 0 && (K > 64 || C % 32 != 0)) return launch3_dma<128, 16>(p, s);
+    if (K <= 64 && C == 64) return launch3_dma<64, 32, true>(p, s);   // both weight stages resident in LDS
     if (K <= D_BIAS_MAX && C % 32 == 0) return launch3_dma<64, 32>(p, s);
     if (K <= 64 && C % 32 == 0) {
         p.ktiles = (K + 63) / 64;

@@ -216,7 +216,16 @@ class TransformerStackFn(torch.autograd.Function):
         nhead, p_drop, seed, T = ctx.cfg
         L = len(ctx.ws) // 12
         g = ops.mean_t_bwd(dout.contiguous().float(), T)
-        dws = [torch.zeros_like(w) if w.dim() == 1 else torch.empty_like(w) for w in ctx.ws]
+        # vector gradients are accumulated with atomics: one zero fill for all of them
+        vecs = [w for w in ctx.ws if w.dim() == 1]
+        zbuf = torch.zeros(sum((w.numel() + 3) // 4 * 4 for w in vecs), device=g.device, dtype=torch.float32)
+        dws, pos = [], 0
+        for w in ctx.ws:
+            if w.dim() == 1:
+                dws.append(zbuf[pos:pos + w.numel()])
+                pos += (w.numel() + 3) // 4 * 4
+            else:
+                dws.append(torch.empty_like(w))
         for l in range(L - 1, -1, -1):
             g = ops.transformer_layer_bwd(ctx.inputs[l], g, ctx.ws[12 * l: 12 * l + 12], dws[12 * l: 12 * l + 12],
                                           ctx.saves[l], nhead, p_drop, seed + 7919 * l)
@@ -271,8 +280,11 @@ class DecoderFn(torch.autograd.Function):
         Hp = ops.roundup(Hc, 8)
         src = ops.nchw_to_nhwc(x.contiguous().float(), cdtype, C)
         # rows (tap, k): w9[t * Hp + k][c] = w1[k][c][t]; padded output channels are zero rows
-        w9 = torch.zeros((9, Hp, C), device=x.device, dtype=torch.float32)
-        w9[:, :Hc] = w1.detach().reshape(Hc, C, 9).permute(2, 0, 1)
+        if Hp == Hc:
+            w9 = w1.detach().reshape(Hc, C, 9).permute(2, 0, 1).contiguous()
+        else:
+            w9 = torch.zeros((9, Hp, C), device=x.device, dtype=torch.float32)
+            w9[:, :Hc] = w1.detach().reshape(Hc, C, 9).permute(2, 0, 1)
         w9 = w9.view(9 * Hp, C, 1, 1)
         w9p = ops.pack_conv_weight(w9, cdtype, [0], False, 9 * Hp, C)
         y9 = torch.empty((B, h, w, 9 * Hp), device=x.device, dtype=torch.float32)

@@ -224,7 +224,8 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
         if rec is None:
             # every launch of the persistent kernel, by variant (same rule as sf_conv3x3's dispatch)
             wide = K <= 1024 and (K > 64 or C % 32 != 0)
-            rec = TIMED.get("conv3_dma_wide_kernel" if wide else "conv3_dma_kernel") if (wide or C % 32 == 0) else None
+            name = "conv3_dma_wide_kernel" if wide else ("conv3_dma_res_kernel" if C == 64 else "conv3_dma_kernel")
+            rec = TIMED.get(name) if (wide or C % 32 == 0) else None
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
