@@ -6,6 +6,7 @@ There is no CPU or eager-PyTorch fallback: without the built library or without 
 modules raise.
 """
 from . import ops
+from .evaluation import Evaluator, calculate_metrics, calculate_psnr, calculate_ssim, merge_partials
 from .functional import compute_dtype, set_compute_dtype
 from .modules import (CNNEncoder, CombinedLoss, GANLoss, ImageLoss, LSTMModule, PatchDiscriminator,
                       PositionalEncoding, SimpleUpsamplingDecoder, StationLoss, StreamflowPredictionModel,
@@ -13,4 +14,5 @@ from .modules import (CNNEncoder, CombinedLoss, GANLoss, ImageLoss, LSTMModule, 
 
 __all__ = ["ops", "compute_dtype", "set_compute_dtype", "CNNEncoder", "CombinedLoss", "GANLoss", "ImageLoss",
            "LSTMModule", "PatchDiscriminator", "PositionalEncoding", "SimpleUpsamplingDecoder", "StationLoss",
-           "StreamflowPredictionModel", "TransformerModule"]
+           "StreamflowPredictionModel", "TransformerModule", "Evaluator", "calculate_metrics", "calculate_psnr",
+           "calculate_ssim", "merge_partials"]

@@ -212,6 +212,32 @@ class Trainer:
         self.batch_idx += 1
         return ld
 
+    def validate(self, batches) -> Dict[str, float]:
+        """Trainer.validate (src/train.py:307-358): eval-mode forward over an iterable of batches
+        (dicts with images, output_image, station_positions, stations), mean combined loss and
+        calculate_metrics of all predictions against the targets (resized to the prediction grid
+        when the shapes differ).  The loss is accumulated on the device: one host sync at the end."""
+        from .evaluation import calculate_metrics, resize_bilinear
+        self.model.eval()
+        total = torch.zeros((), device=self.device)
+        preds, tgts, n = [], [], 0
+        with torch.no_grad():
+            for b in batches:
+                images = b["images"].to(self.device, non_blocking=True)
+                target = b["output_image"].to(self.device, non_blocking=True)
+                pred = self.model(images)
+                total += self.loss_fn(pred, target, b["station_positions"], b["stations"])["total"].float()
+                n += 1
+                pc = pred.float().cpu()
+                tc = target.float().cpu()
+                if tc.shape != pc.shape:
+                    tc = resize_bilinear(tc, pc.shape[2], pc.shape[3], self.device)
+                preds.append(pc)
+                tgts.append(tc)
+        metrics = calculate_metrics(torch.cat(preds), torch.cat(tgts))
+        metrics["loss"] = float(total.item()) / max(n, 1)
+        return metrics
+
     def saw_nan_or_inf(self) -> bool:
         """Host-synchronising read of the flag the three per-step checks of src/train.py:193,198,221 feed."""
         bad = bool(self.nan_flag.item())

@@ -650,3 +650,63 @@ def test_enc1_fused_layer_against_separate_kernels(sf):
         close(dbeta, dbeta_ref.cpu().numpy(), 2e-3)
         close(dgamma, dgamma_ref.cpu().numpy(), 2e-3)
         close(dw, dw_ref.cpu().numpy(), 2e-2)
+
+
+def test_evaluator_against_reference_metrics(sf):
+    """Evaluator.evaluate_dataset on the HIP model (eval mode, f32, LSTM generator) against the
+    metrics the reference's Evaluator.evaluate_dataset produced for the same weights and samples
+    (src/evaluate.py:149-335): image-level and station metrics to 1e-4 / 3 decimals (NSE, RMSE),
+    batched and date-sharded forwarding included; the target is resized on the GPU."""
+    g = golden("evaluate")
+    cfg = {"data": {"upscale_factor": 2, "image_size": [int(g["images0"].shape[-2]), int(g["images0"].shape[-1])],
+                    "window_size": int(g["images0"].shape[0])},
+           "model": {"input_channels": int(g["images0"].shape[1]), "hidden_dim": 16, "num_layers": 2,
+                     "temporal_module": "LSTM"},
+           "stations": {"kernel_size": 3}}
+    m = sf.StreamflowPredictionModel(cfg).to(DEV)
+    load_gold(m, "eval_g")
+    ds = [{"images": torch.from_numpy(g[f"images{i}"]), "output_image": torch.from_numpy(g[f"target{i}"]),
+           "stations": torch.from_numpy(g[f"stations{i}"]), "station_positions": torch.from_numpy(g[f"pos{i}"])}
+          for i in range(int(g["n"]))]
+    ev = sf.Evaluator(cfg, model=m)
+    keys, skeys = ("RMSE", "MAE", "SSIM", "PSNR", "Correlation"), ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE")
+    for kwargs in ({"batch_size": 1}, {"batch_size": 3}):
+        res = ev.evaluate_dataset(ds, **kwargs)
+        np.testing.assert_allclose([res[k] for k in keys], g["metrics"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose([res["station_metrics"][k] for k in skeys], g["station_metrics"], rtol=1e-4, atol=1e-5)
+    parts = [ev.evaluate_dataset(ds, batch_size=2, shard=(r, 2))["partial"] for r in (0, 1)]
+    res = sf.merge_partials(parts)
+    np.testing.assert_allclose([res[k] for k in keys], g["metrics"], rtol=1e-4, atol=1e-5)
+    assert round(res["station_metrics"]["NSE"], 3) == round(float(g["station_metrics"][3]), 3)
+
+
+def test_trainer_validate(sf):
+    """Trainer.validate (src/train.py:307-358): mean eval-mode loss and calculate_metrics over all
+    batches, against the same quantities put together from single calls and the oracle's metric
+    restatement (targets at half resolution: resized to the prediction grid like the reference)."""
+    import importlib
+    training = importlib.import_module(sf.__name__ + ".training")
+    cfg = gen_cfg(16, "LSTM", 64, 3)
+    cfg.update({"loss": {"metric": "MSE", "weights": {"image": 1.0, "station": 0.5}}, "stations": {"kernel_size": 3},
+                "system": {"mixed_precision": False}, "train": {"lr": 1e-4}})
+    tr = training.Trainer(cfg, device=DEV)
+    torch.manual_seed(2)
+    batches = []
+    for _ in range(3):
+        B = 2
+        batches.append({"images": torch.randn(B, 5, 3, 64, 64), "output_image": torch.randn(B, 1, 64, 64),
+                        "station_positions": [torch.randint(0, 64, (4, 2)) for _ in range(B)],
+                        "stations": [torch.randn(4) for _ in range(B)]})
+    res = tr.validate(batches)
+    tr.model.eval()
+    losses, ps, ts = [], [], []
+    with torch.no_grad():
+        for b in batches:
+            p = tr.model(b["images"].to(DEV))
+            losses.append(float(tr.loss_fn(p, b["output_image"].to(DEV), b["station_positions"], b["stations"])["total"]))
+            ps.append(p.cpu())
+            ts.append(O.bilinear_resize(b["output_image"], 128, 128))
+    assert abs(res["loss"] - np.mean(losses)) <= 1e-5 * max(1.0, abs(np.mean(losses)))
+    want = O.calculate_metrics(torch.cat(ps).numpy(), torch.cat(ts).numpy())
+    for k in ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE"):
+        assert abs(res[k] - want[k]) <= 1e-4 * max(1.0, abs(want[k])), k
