@@ -321,9 +321,10 @@ class DecoderFn(torch.autograd.Function):
         ops.conv3x3(dz2, w2T, dz1, Hp, dgrad=True, aux=h1, aux_mode=1, flop_c=Hc, flop_k=Hc)
         g = ops.upconv3_bwd(dz1, h, w, cdtype).view(B, h, w, 9 * Hp)
         # dW9[(t,k)][c] = sum_pixels g[pixel][(t,k)] * src[pixel][c]
-        dw9 = torch.zeros((9 * Hp, C, 1, 1), device=dy.device, dtype=torch.float32)
-        ops.conv_wgrad(src, g, dw9, ops.conv_geom(B, h, w, C, h, w, 1, 1, h, w, [(0, 0)], tap_rs=[0], cin_real=C, RS=1),
-                       9 * Hp)
+        dw9 = torch.zeros((9 * Hp, C), device=dy.device, dtype=torch.float32)
+        M = B * h * w
+        ops.linear_gemm(g.view(M, 9 * Hp), src.view(M, C), dw9, 9 * Hp, C, M, 9 * Hp, C, C, True, True, ops.OUT_IJ,
+                        max(1, min(32, M // 512)))
         dw1 = dw9.view(9, Hp, C)[:, :Hc].permute(1, 2, 0).reshape(Hc, C, 3, 3)
         # the interpolation weights of a pixel sum to one: the centre tap of g sums to sum_p dz1[p]
         db1 = g.view(-1, 9, Hp)[:, 4, :Hc].float().sum(dim=0)
