@@ -145,41 +145,58 @@ class Evaluator:
         return resize_bilinear(target, OH, OW, self.device)
 
     # -- evaluation ------------------------------------------------------------------------
+    def _date_metrics(self, i: int, s: Dict, p2: np.ndarray, t2: np.ndarray, half: int, pred_dir: Optional[str]):
+        """Host work of one date (src/evaluate.py:205-262): error sums, SSIM / PSNR / correlation,
+        the k x k station means, the optional .npy files."""
+        p, t = p2.reshape(-1), t2.reshape(-1)
+        sse, sae = float(((p - t) ** 2).sum()), float(np.abs(p - t).sum())
+        ps = calculate_psnr(p2, t2)
+        corr = None
+        if p.std() > 1e-10 and t.std() > 1e-10:
+            c = np.corrcoef(p, t)[0, 1]
+            corr = None if np.isnan(c) else float(c)
+        per_date = (i, calculate_ssim(p2, t2), None if np.isinf(ps) else ps, corr)
+        date = s.get("date", f"{i:06d}")
+        if pred_dir is not None:
+            np.save(os.path.join(pred_dir, f"pred_{date}.npy"), p2)
+            np.save(os.path.join(pred_dir, f"target_{date}.npy"), t2)
+        stations = []
+        for j, (pos, r) in enumerate(zip(s["station_positions"], s["stations"])):
+            px, py = int(pos[0]), int(pos[1])
+            y0, y1 = max(0, py - half), min(p2.shape[0], py + half + 1)
+            x0, x1 = max(0, px - half), min(p2.shape[1], px + half + 1)
+            stations.append(((i, j), date, px, py, float(r), float(p2[y0:y1, x0:x1].mean())))
+        return sse, sae, p.size, per_date, stations
+
     def evaluate_partial(self, dataset: Sequence[Dict], indices: Sequence[int], batch_size: int = 16,
-                         pred_dir: Optional[str] = None) -> Dict:
-        """Metrics contributions of dataset[i] for i in indices (src/evaluate.py:186-268)."""
+                         pred_dir: Optional[str] = None, workers: Optional[int] = None) -> Dict:
+        """Metrics contributions of dataset[i] for i in indices (src/evaluate.py:186-268).  The
+        per-date host metrics (SciPy filters dominate) run on a thread pool while the GPU forwards
+        the next batch; results are collected in index order, so the sums do not depend on timing."""
+        from concurrent.futures import ThreadPoolExecutor
         part = _new_partial()
         half = self.config.get("stations", {}).get("kernel_size", 3) // 2
         idx = list(indices)
-        for b0 in range(0, len(idx), batch_size):
-            chunk = idx[b0:b0 + batch_size]
-            samples = [dataset[i] for i in chunk]
-            preds = self.predict_batch(torch.stack([s["images"] for s in samples]))
-            tgts = torch.stack([s["output_image"] for s in samples]).float()
-            if tgts.shape != preds.shape:
-                tgts = self._resize_targets(tgts, preds.shape[2], preds.shape[3])
-            for i, s, pr, tg in zip(chunk, samples, preds.numpy(), tgts.numpy()):
-                p2, t2 = pr[0], tg[0]
-                p, t = p2.reshape(-1), t2.reshape(-1)
-                part["sse"] += float(((p - t) ** 2).sum())
-                part["sae"] += float(np.abs(p - t).sum())
-                part["npx"] += p.size
-                ps = calculate_psnr(p2, t2)
-                corr = None
-                if p.std() > 1e-10 and t.std() > 1e-10:
-                    c = np.corrcoef(p, t)[0, 1]
-                    corr = None if np.isnan(c) else float(c)
-                part["per_date"].append((i, calculate_ssim(p2, t2), None if np.isinf(ps) else ps, corr))
-                if pred_dir is not None:
-                    date = s.get("date", f"{i:06d}")
-                    np.save(os.path.join(pred_dir, f"pred_{date}.npy"), p2)
-                    np.save(os.path.join(pred_dir, f"target_{date}.npy"), t2)
-                for j, (pos, r) in enumerate(zip(s["station_positions"], s["stations"])):
-                    px, py = int(pos[0]), int(pos[1])
-                    y0, y1 = max(0, py - half), min(p2.shape[0], py + half + 1)
-                    x0, x1 = max(0, px - half), min(p2.shape[1], px + half + 1)
-                    part["stations"].append(((i, j), s.get("date", f"{i:06d}"), px, py, float(r),
-                                             float(p2[y0:y1, x0:x1].mean())))
+        if workers is None:
+            workers = max(1, min(16, os.cpu_count() or 1))
+        futures = []
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for b0 in range(0, len(idx), batch_size):
+                chunk = idx[b0:b0 + batch_size]
+                samples = [dataset[i] for i in chunk]
+                preds = self.predict_batch(torch.stack([s["images"] for s in samples]))
+                tgts = torch.stack([s["output_image"] for s in samples]).float()
+                if tgts.shape != preds.shape:
+                    tgts = self._resize_targets(tgts, preds.shape[2], preds.shape[3])
+                for i, s, pr, tg in zip(chunk, samples, preds.numpy(), tgts.numpy()):
+                    futures.append(pool.submit(self._date_metrics, i, s, pr[0], tg[0], half, pred_dir))
+            for f in futures:
+                sse, sae, npx, per_date, stations = f.result()
+                part["sse"] += sse
+                part["sae"] += sae
+                part["npx"] += npx
+                part["per_date"].append(per_date)
+                part["stations"] += stations
         return part
 
     def evaluate_dataset(self, dataset: Sequence[Dict], output_dir: Optional[str] = None, batch_size: int = 16,
