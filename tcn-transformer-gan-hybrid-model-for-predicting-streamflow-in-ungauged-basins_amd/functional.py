@@ -377,8 +377,24 @@ class DiscriminatorFn(torch.autograd.Function):
     statistics and updates its running buffers, as the reference never puts D in eval mode."""
 
     @staticmethod
-    def forward(ctx, x, cdtype, training, w1, b1, *rest):
+    def forward(ctx, x, cdtype, training, reuse, w1, b1, *rest):
         # rest = 3 x (w, b, gamma, beta, rm, rv) + (w5, b5)
+        # `reuse`: the record of an earlier forward of the SAME input with the SAME parameters
+        # (DiscriminatorFn.last_record): nothing is recomputed, only the BatchNorm running
+        # statistics are updated again, as a second forward call would.
+        if reuse is not None:
+            if tuple(reuse["x"].shape) != tuple(x.shape):
+                raise ValueError("DiscriminatorFn: the reused forward record belongs to another input shape")
+            for i in range(3):
+                wt, b, gamma, beta, rm, rv = rest[6 * i: 6 * i + 6]
+                K = wt.shape[0]
+                z = reuse["zs"][i]
+                ops.bn_finalize(reuse["wss"][i], z.shape[0] * z.shape[1] * z.shape[2], K, K, gamma.detach(), beta.detach(),
+                                rm, rv, True)
+            ctx.x, ctx.acts, ctx.zs, ctx.sts = reuse["x"], reuse["acts"], reuse["zs"], reuse["sts"]
+            ctx.params = (w1, b1, *rest)
+            ctx.cdtype = cdtype
+            return reuse["out"].clone()
         N, _, H, W = x.shape
         x = x.contiguous().float()
         w1c, b1c = w1.detach().contiguous(), b1.detach().contiguous()
@@ -387,7 +403,7 @@ class DiscriminatorFn(torch.autograd.Function):
             raise NotImplementedError("discriminator width must be a multiple of 8 on the HIP path")
         y = ops.dconv1_fwd(x, w1c, b1c, cdtype)
         acts = [y]
-        zs, sts = [], []
+        zs, sts, wss = [], [], []
         for i in range(3):
             wt, b, gamma, beta, rm, rv = rest[6 * i: 6 * i + 6]
             K, C = wt.shape[0], y.shape[-1]
@@ -404,6 +420,7 @@ class DiscriminatorFn(torch.autograd.Function):
             st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, True)
             y = ops.bn_lrelu_fwd(z, st)
             zs.append(z)
+            wss.append(ws)
             sts.append(st)
             acts.append(y)
         w5, b5 = rest[18], rest[19]
@@ -412,7 +429,10 @@ class DiscriminatorFn(torch.autograd.Function):
         ctx.x, ctx.acts, ctx.zs, ctx.sts = x, acts, zs, sts
         ctx.params = (w1, b1, *rest)
         ctx.cdtype = cdtype
+        DiscriminatorFn.last_record = {"x": x, "acts": acts, "zs": zs, "sts": sts, "wss": wss, "out": out}
         return out
+
+    last_record = None   # activations of the most recent full forward (see `reuse`)
 
     @staticmethod
     def backward(ctx, dout):
@@ -425,7 +445,7 @@ class DiscriminatorFn(torch.autograd.Function):
         y4 = acts[3]
         # parameter gradients are skipped as a whole when no parameter asks for one (the trainer
         # turns them off for batches whose discriminator gradients would be zeroed unused)
-        need_w = any(ctx.needs_input_grad[3:])
+        need_w = any(ctx.needs_input_grad[4:])
         if need_w:
             dw5, db5 = ops.conv_k1_bwd_weight(y4, dout, w5.shape[1], 4, 1)
             grads[2 + 18], grads[2 + 19] = dw5, db5
@@ -459,7 +479,7 @@ class DiscriminatorFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.dconv1_bwd_data(dy, w1.detach().contiguous(), x.shape[2], x.shape[3])
         ctx.x = ctx.acts = ctx.zs = ctx.sts = None
-        return (dx, None, None, *grads)
+        return (dx, None, None, None, *grads)
 
 
 # ------------------------------------------------------------------------------ losses

@@ -274,7 +274,10 @@ class PatchDiscriminator(nn.Module):
             conv_block(hc, hc * 2), conv_block(hc * 2, hc * 4), conv_block(hc * 4, hc * 8),
             nn.Conv2d(hc * 8, 1, kernel_size=4, stride=1, padding=1))
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, reuse=None) -> torch.Tensor:
+        """`reuse`: the `last_record` taken after an earlier call on the same input while the
+        parameters have not changed -- the forward is then not recomputed (the BatchNorm running
+        statistics still advance as for a second call)."""
         _need_cuda(x, "PatchDiscriminator")
         m = self.model
         ps = [m[0].weight, m[0].bias]
@@ -283,7 +286,11 @@ class PatchDiscriminator(nn.Module):
             ps += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
             bn.num_batches_tracked += 1
         ps += [m[5].weight, m[5].bias]
-        return SF.DiscriminatorFn.apply(x.float(), SF.compute_dtype(), True, *ps)
+        out = SF.DiscriminatorFn.apply(x.float(), SF.compute_dtype(), True, reuse, *ps)
+        if reuse is None:
+            self.last_record = SF.DiscriminatorFn.last_record
+            SF.DiscriminatorFn.last_record = None
+        return out
 
 
 class _BceWithLogits(nn.Module):

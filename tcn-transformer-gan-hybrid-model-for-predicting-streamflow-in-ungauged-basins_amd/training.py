@@ -177,6 +177,7 @@ class Trainer:
             loss_g = ld["total"]
             if self.use_gan:
                 pred_fake = self.discriminator(pred)
+                fake_record = self.discriminator.last_record
                 g_gan = self.gan_loss_fn.gan_loss(pred_fake, torch.ones(1, device=self.device))
                 loss_g = loss_g + self.gan_weight * g_gan
                 ld["gan_g"] = g_gan
@@ -185,7 +186,9 @@ class Trainer:
         if d_batch:
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp), torch.set_grad_enabled(d_live):
                 pred_real = self.discriminator(output_image)
-                pred_fake_d = self.discriminator(pred.detach())
+                # D(pred.detach()) repeats D(pred) of the generator loss above (same input, same
+                # parameters: no optimiser step in between): its activations are reused
+                pred_fake_d = self.discriminator(pred.detach(), reuse=fake_record)
                 loss_d = self.gan_loss_fn.discriminator_loss(pred_real, pred_fake_d)
                 ld["gan_d"] = loss_d
             if d_live:
@@ -209,6 +212,8 @@ class Trainer:
             self.opt_g.zero_grad()
             if self.use_gan:
                 self.opt_d.zero_grad()
+        if self.use_gan:
+            self.discriminator.last_record = None
         self.batch_idx += 1
         return ld
 
