@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange-rehearsal", action="store_true",
+                    help="N=1 only: run the data-parallel gradient exchange (RCCL process group of one rank, hooks, "
+                         "flat-buffer all-reduce) that N>1 uses, to rehearse that code on a one-GPU box")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,6 +82,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
+    rehearse = a.exchange_rehearsal and world == 1
+    if rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     sf = importlib.import_module(PKG)
@@ -99,7 +107,7 @@ def main():
     batches = synth.make_batches(3, a.batch, seed=rank, lonlat_to_pixel=l2p)
     dev_batches = [{"images": b["images"].cuda(), "output_image": b["output_image"].cuda(),
                     "station_positions": b["station_positions"], "stations": b["stations"]} for b in batches]
-    trainer = training.Trainer(cfg, device=f"cuda:{local}")
+    trainer = training.Trainer(cfg, device=f"cuda:{local}", distributed=True if rehearse else None)
 
     def step(i):
         b = dev_batches[i % len(dev_batches)]
@@ -128,7 +136,7 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(ld["total"])
+    loss = float(ld["total"].detach())
     bad = trainer.saw_nan_or_inf()
     dom_stats = ops.timed_tflops(dom)
     del ops.TIMED[dom]
@@ -165,10 +173,12 @@ def main():
                          "kernel": dom, "launches": n_l, "ms_per_launch": round(ms_l, 4), "other": others},
             "final_loss": round(loss, 6), "nan_or_inf": bad,
         }
+        if rehearse:
+            out["exchange_rehearsal"] = True
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, batches)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
 
 

@@ -110,11 +110,12 @@ class Trainer:
         self.use_amp = bool(scfg.get("mixed_precision", True))
         self.accum = int(scfg.get("grad_accum_steps", 1))
         self.d_update_interval = 3  # src/train.py:101
-        self.opt_g = FlatAdam(self.model, lr)
+        big = int(scfg.get("big_grad_numel", 1 << 22))  # gradients this large skip the flat gradient buffer
+        self.opt_g = FlatAdam(self.model, lr, big_numel=big)
         if self.use_gan:
             self.discriminator = PatchDiscriminator(1, 64).to(self.device)
             self.gan_loss_fn = GANLoss(lambda_gan=self.gan_weight, lambda_pixel=1.0)
-            self.opt_d = FlatAdam(self.discriminator, lr * 0.2, betas=(0.5, 0.999))
+            self.opt_d = FlatAdam(self.discriminator, lr * 0.2, betas=(0.5, 0.999), big_numel=big)
         self.batch_idx = 0
         self._d_req = True
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed

@@ -1,0 +1,103 @@
+"""Data-parallel train step on the GPU: two ranks (one process each, both on cuda:0, gloo
+carrying the device tensors) run training.Trainer.train_step with the exchange path the
+multi-GPU bench uses: big gradients all-reduced in place from post-accumulate hooks during
+backward, all other gradients in one flat buffer, the 1/world scale folded into the Adam launch.
+src/train.py has no data-parallel path; the properties checked are those of synchronous
+gradient averaging."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import goldgen as G
+from conftest import close, load_pkg
+from test_gpu_parity import load_gold, make_batches, train_cfg
+
+pytestmark = pytest.mark.gpu
+STEPS = 4
+
+
+def _cfg():
+    cfg = train_cfg("Transformer", True, 1)
+    cfg["system"]["big_grad_numel"] = 50000   # the temporal input Linear weight takes the hook path
+    return cfg
+
+
+def _run(sf, distributed, batches):
+    training = importlib.import_module(sf.__name__ + ".training")
+    tr = training.Trainer(_cfg(), device="cuda", distributed=distributed)
+    assert len(tr.opt_g.big) >= 1 and len(tr.opt_g.small) >= 10
+    load_gold(tr.model, "trn_g_trgan")
+    load_gold(tr.discriminator, "trn_d_trgan")
+    tr.model.temporal_module.dropout = 0.0
+    losses = []
+    for b in batches:
+        o = tr.train_step(b["images"], b["output_image"], b["station_positions"], b["stations"])
+        losses.append(float(o["total"].detach()))
+    torch.cuda.synchronize()
+    assert not tr.saw_nan_or_inf()
+    return tr.opt_g.flat.cpu(), tr.opt_d.flat.cpu(), losses
+
+
+def _worker(rank, world, port, same_data, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # Test transport only: gloo stages device tensors through pinned host memory on a side stream,
+    # and with two processes sharing one GPU that path stalls unless the producing stream has
+    # drained (observed: the third step's first reduce never completes).  RCCL, which the real
+    # multi-GPU run uses, is stream ordered and needs no such sync.
+    real = dist.all_reduce
+
+    def synced_all_reduce(t, *args, **kw):
+        torch.cuda.synchronize()
+        return real(t, *args, **kw)
+
+    dist.all_reduce = synced_all_reduce
+    try:
+        sf = load_pkg()
+        batches = make_batches(2 * STEPS, 2, 3, 64)
+        mine = batches[:STEPS] if (same_data or rank == 0) else batches[STEPS:]
+        out[rank] = _run(sf, True, mine)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(same_data):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, port, same_data, out), nprocs=2, join=True)
+    return out[0], out[1]
+
+
+def test_two_ranks_stay_in_lockstep_on_different_data():
+    """Every gradient element is exchanged: after four steps (discriminator batches included)
+    on different data both ranks hold bit-identical generator and discriminator parameters."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    (g0, d0, l0), (g1, d1, l1) = _spawn(same_data=False)
+    assert torch.equal(g0, g1) and torch.equal(d0, d1)
+    assert l0 != l1                      # the ranks did see different batches
+    assert np.isfinite(l0 + l1).all()
+
+
+def test_two_ranks_on_the_same_data_match_one_process():
+    """The average of two equal gradients is that gradient: the two-rank run must reproduce the
+    single-process run (same tolerance as the reference-trajectory test: f32 atomics order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    (g0, d0, l0), (g1, d1, _) = _spawn(same_data=True)
+    assert torch.equal(g0, g1) and torch.equal(d0, d1)
+    gs, ds, ls = _run(load_pkg(), False, make_batches(2 * STEPS, 2, 3, 64)[:STEPS])
+    np.testing.assert_allclose(l0, ls, rtol=5e-4)
+    close(g0, gs.numpy(), 2e-3)
+    close(d0, ds.numpy(), 2e-3)
