@@ -323,6 +323,32 @@ int sf_adam(float* p, const float* g, float* m, float* v, long long n, float lr,
 /* flag[0] |= 1 if any element of x is NaN/Inf (src/train.py:193,198,221) */
 int sf_nan_inf_flag(const float* x, long long n, int* flag, void* stream);
 
+/* ---- device-resident dataset ---------------------------------------------------------------- */
+/* Per (date, channel) statistics of frames f32 [D,C,HW] held on the device, the per-date loop
+ * of StreamflowDataset._compute_statistics (src/dataset.py:219-264): out f64 [D,C,4] = sum, sum
+ * of float32 squares, min, max over the selected pixels (mask > 0.5 where mask_row[d] >= 0
+ * names a row of masks f32 [n_masks,HW]; every pixel otherwise), NaN -> 0 and +-Inf -> +-FLT_MAX
+ * first (numpy.nan_to_num defaults, :252-254).  count i64 [D] = selected pixels; bad0 i32 [D] =
+ * non-finite values in channel 0.  masks and mask_row are both NULL when no date has a mask. */
+int sf_dataset_plane_stats(const float* frames, const float* masks, const int* mask_row, int D,
+                           int C, long long HW, double* out, long long* count, int* bad0,
+                           void* stream);
+/* The per-frame arithmetic of StreamflowDataset.__getitem__ (src/dataset.py:412-435,474-491)
+ * applied once to every resident frame, in place: multiply by the date's mask, non-finite -> 0,
+ * |channel 0| < flow_threshold -> 0, then (normalize != 0) (v - a[c]) / b[c] evaluated in
+ * float64 and rounded to float32 (a, b device f64 [C]: mean/std, or min/(max-min)).  target
+ * (nullable, f32 [D,HW]) receives channel 0 as the reference prepares its output image
+ * (:441-472,487,491): mask and threshold, no NaN replacement, same normalisation. */
+int sf_dataset_transform(float* frames, float* target, const float* masks, const int* mask_row,
+                         const double* a, const double* b, int normalize, float flow_threshold,
+                         int D, int C, long long HW, void* stream);
+/* dst frame i (n_elems floats, contiguous) = src frame rows[i] (frames src_stride floats apart,
+ * n_src of them; rows device i64 [n]; a row outside [0,n_src) leaves its frame untouched): the
+ * stacking of np.stack / the collate function (src/dataset.py:438, src/train.py:381-382) for
+ * windows served from the resident frames.  16-byte accesses when sizes and bases allow. */
+int sf_gather_frames(const float* src, long long src_stride, long long n_src,
+                     const long long* rows, int n, long long n_elems, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -483,9 +483,35 @@ class DiscriminatorFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------ losses
+class PackedStations:
+    """Station rows of one batch in the layout sf_image_station_loss reads: int32 [S,2] positions
+    (x, y), f32 [S] runoffs, int32 [B+1] sample offsets, all on the device, and the host-side
+    total S.  A loss module given one of these (as positions, runoffs or both) skips packing."""
+
+    def __init__(self, pos: torch.Tensor, run: torch.Tensor, offs: torch.Tensor, S: int):
+        self.pos, self.run, self.offs, self.S = pos, run, offs, int(S)
+
+    @classmethod
+    def from_host(cls, pos, run, counts, device) -> "PackedStations":
+        """pos int [S,2], run float [S], counts int [B] (numpy) -> one host-to-device copy."""
+        import numpy as np
+        S, B = int(np.sum(counts)), len(counts)
+        n = max(S, 1)
+        buf = np.zeros(3 * n + B + 1, dtype=np.int32)
+        if S:
+            buf[: 2 * S] = np.asarray(pos, dtype=np.int32).reshape(-1)
+            buf[2 * n: 2 * n + S] = np.asarray(run, dtype=np.float32).reshape(-1).view(np.int32)
+        buf[3 * n + 1:] = np.cumsum(counts)
+        d = torch.from_numpy(buf).to(device, non_blocking=True)
+        return cls(d[: 2 * n].view(-1, 2), d[2 * n: 3 * n].view(torch.float32), d[3 * n:], S)
+
+
 def pack_stations(positions: Sequence[torch.Tensor], runoffs: Sequence[torch.Tensor], device):
     """List-of-tensors station batch (src/train.py:181-188) -> packed device arrays with ONE
     host-to-device copy: int32 [S,2] positions, f32 [S] runoffs, int32 [B+1] offsets."""
+    for packed in (positions, runoffs):
+        if isinstance(packed, PackedStations):
+            return packed.pos, packed.run, packed.offs, packed.S
     B = len(positions)
     counts = [int(r.numel()) for r in runoffs]
     S = sum(counts)

@@ -69,7 +69,8 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
-           "sf_bce_logits", "sf_adam", "sf_nan_inf_flag"]
+           "sf_bce_logits", "sf_adam", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
+           "sf_gather_frames"]
 
 
 def _check(rc: int, who: str):
@@ -729,3 +730,38 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
 def nan_inf_flag(x: torch.Tensor, flag: torch.Tensor):
     _dev(x, flag, dtypes=[torch.float32, torch.int32])
     _check(lib().sf_nan_inf_flag(_p(x), _c_ll(x.numel()), _p(flag), _stream()), "sf_nan_inf_flag")
+
+
+# ------------------------------------------------------------------------------ resident dataset
+def dataset_plane_stats(frames: torch.Tensor, masks: Optional[torch.Tensor], mask_row: Optional[torch.Tensor]):
+    """frames f32 [D,C,H,W] -> (stats f64 [D,C,4] = sum, sumsq, min, max; count i64 [D]; bad0 i32 [D])."""
+    _dev(frames, masks, mask_row, dtypes=[torch.float32, torch.float32, torch.int32])
+    D, C, H, W = frames.shape
+    out = torch.empty((D, C, 4), device=frames.device, dtype=torch.float64)
+    count = torch.empty(D, device=frames.device, dtype=torch.int64)
+    bad0 = torch.empty(D, device=frames.device, dtype=torch.int32)
+    _check(lib().sf_dataset_plane_stats(_p(frames), _p(masks), _p(mask_row), D, C, ctypes.c_longlong(H * W), _p(out),
+                                        _p(count), _p(bad0), _stream()), "sf_dataset_plane_stats")
+    return out, count, bad0
+
+
+def dataset_transform(frames: torch.Tensor, target: Optional[torch.Tensor], masks: Optional[torch.Tensor],
+                      mask_row: Optional[torch.Tensor], a: Optional[torch.Tensor], b: Optional[torch.Tensor],
+                      flow_threshold: float):
+    """In place on frames f32 [D,C,H,W]; target (optional) f32 [D,1,H,W]."""
+    _dev(frames, target, masks, mask_row, a, b,
+         dtypes=[torch.float32, torch.float32, torch.float32, torch.int32, torch.float64, torch.float64])
+    D, C, H, W = frames.shape
+    _check(lib().sf_dataset_transform(_p(frames), _p(target), _p(masks), _p(mask_row), _p(a), _p(b),
+                                      1 if a is not None else 0, _c_f(flow_threshold), D, C, ctypes.c_longlong(H * W),
+                                      _stream()), "sf_dataset_transform")
+
+
+def gather_frames(src: torch.Tensor, src_stride: int, n_src: int, rows: torch.Tensor, n_elems: int, out: torch.Tensor):
+    """out[i].flat = src.flat[rows[i] * src_stride : ... + n_elems] (rows: device int64)."""
+    _dev(src, rows, out, dtypes=[torch.float32, torch.int64, torch.float32])
+    n = rows.numel()
+    assert out.numel() == n * n_elems and src.numel() >= (n_src - 1) * src_stride + n_elems
+    _check(lib().sf_gather_frames(_p(src), ctypes.c_longlong(src_stride), ctypes.c_longlong(n_src), _p(rows), n,
+                                  ctypes.c_longlong(n_elems), _p(out), _stream()), "sf_gather_frames")
+    return out

@@ -94,3 +94,41 @@ def pixel_sweep(region, width: int, height: int, n_random: int = 3000):
     lon = np.concatenate([lon, tie_lon[:n], edge_lon, tie_lon[:n][::-1]])
     lat = np.concatenate([lat, tie_lat[:n], edge_lat, tie_lat[:n]])
     return lon.astype(np.float64), lat.astype(np.float64)
+
+
+DATASET_CASES = {
+    "A": {"window_size": 5, "normalization_type": "z_score"},
+    "B": {"window_size": 3, "normalization_type": "minmax"},
+}
+DATASET_STATIONS = ["st_b", "st_a", "gauge10", "x9"]
+
+
+def dataset_case(g, tag):
+    """Raw inputs of dataset case `tag` from the dataset.npz fixture: frames [D,C,h,w], masks
+    {date index: [h,w] uint8}, dates (file stems), stations {name: (timestamps as str, lon, lat,
+    runoff)} and the config the reference ran with."""
+    frames = g[f"{tag}_frames"]
+    masks = {int(d): g[f"{tag}_masks"][i] for i, d in enumerate(g[f"{tag}_mask_idx"])}
+    dates = [f"202001{d + 1:02d}" for d in range(frames.shape[0])]
+    stations = {}
+    for n in DATASET_STATIONS:
+        a = g[f"{tag}_st_{n}"]
+        stations[n] = ([str(int(t)) for t in a[0]], a[1], a[2], a[3])
+    cfg = {"data": {"upscale_factor": 2, "region": [100, 110, 25, 35], "flow_threshold": 0.1, "image_size": [20, 24],
+                    **DATASET_CASES[tag]}}
+    return frames, masks, dates, stations, cfg
+
+
+def write_dataset_case(root, frames, masks, dates, stations):
+    """The directory layout StreamflowDataset reads (src/dataset.py:54-57,88-91)."""
+    import os
+    import pandas as pd
+    os.makedirs(os.path.join(root, "images"))
+    os.makedirs(os.path.join(root, "stations"))
+    for d, name in enumerate(dates):
+        np.save(os.path.join(root, "images", name + ".npy"), frames[d])
+        if d in masks:
+            np.save(os.path.join(root, "images", name + "_mask.npy"), masks[d])
+    for n, (ts, lon, lat, run) in stations.items():
+        pd.DataFrame({"timestamp": [int(t) for t in ts], "lon": lon, "lat": lat, "runoff": run}).to_csv(
+            os.path.join(root, "stations", n + ".csv"), index=False)

@@ -384,11 +384,97 @@ def gen_evaluate():
     save("evaluate", **out)
 
 
+def dataset_case(tag):
+    """Raw inputs of one dataset case (formula/seeded; written to disk for the reference to read)."""
+    rs = np.random.RandomState({"A": 11, "B": 12}[tag])
+    if tag == "A":
+        D, C, h, w, size, T, norm = 9, 3, 20, 24, [20, 24], 5, "z_score"
+    else:
+        D, C, h, w, size, T, norm = 8, 2, 12, 16, [20, 24], 3, "minmax"
+    frames = rs.gamma(0.6, 2.0, size=(D, C, h, w)).astype(np.float32)   # many values below the 0.1 flow threshold
+    frames[np.abs(np.abs(frames) - 0.1) < 1e-3] = 0.25                  # keep clear of the threshold itself
+    frames[:, 1:] += rs.standard_normal((D, C - 1, h, w)).astype(np.float32) * 3.0
+    if tag == "A":
+        frames[1, 1, 3, 4] = np.nan          # an input-only channel
+        frames[6, 0, 7, 7] = np.nan          # channel 0 of a date that is also a target
+        frames[3, 2, 0, 0] = np.nan
+    masks = {}
+    for d in ([2, 6] if tag == "A" else [5]):
+        masks[d] = (rs.uniform(size=(h, w)) > 0.3).astype(np.uint8)
+    dates = [f"202001{d + 1:02d}" for d in range(D)]
+    names = ["st_b", "st_a", "gauge10", "x9"]
+    stations = {}
+    for i, n in enumerate(names):
+        ts = list(dates)
+        lon = np.full(D, 100.3 + 2.9 * i) + (rs.uniform(size=D) * 3.0 if i == 2 else 0.0)   # one station moves
+        lat = np.full(D, 34.6 - 2.6 * i)
+        run = rs.gamma(2.0, 30.0, size=D)
+        if i == 3:                                   # rows missing on some dates
+            keep = [k for k in range(D) if k % 3 != 0]
+            ts, lon, lat, run = [ts[k] for k in keep], lon[keep], lat[keep], run[keep]
+        if i == 1:                                   # duplicate date: the first row wins
+            ts = ts + [ts[-1]]
+            lon, lat, run = np.append(lon, 101.0), np.append(lat, 30.0), np.append(run, 7.0)
+        stations[n] = (np.array([int(t) for t in ts]), np.asarray(lon), np.asarray(lat), np.asarray(run))
+    cfg = {"data": {"window_size": T, "upscale_factor": 2, "region": [100, 110, 25, 35], "flow_threshold": 0.1,
+                    "image_size": size, "normalization_type": norm}}
+    return frames, masks, dates, stations, cfg
+
+
+def write_dataset_case(root, frames, masks, dates, stations):
+    import pandas as pd
+    os.makedirs(os.path.join(root, "images"))
+    os.makedirs(os.path.join(root, "stations"))
+    for d, name in enumerate(dates):
+        np.save(os.path.join(root, "images", name + ".npy"), frames[d])
+        if d in masks:
+            np.save(os.path.join(root, "images", name + "_mask.npy"), masks[d])
+    for n, (ts, lon, lat, run) in stations.items():
+        pd.DataFrame({"timestamp": ts, "lon": lon, "lat": lat, "runoff": run}).to_csv(
+            os.path.join(root, "stations", n + ".csv"), index=False)
+
+
+def gen_dataset():
+    """StreamflowDataset (src/dataset.py) on two small synthetic directories: statistics and every
+    sample.  The raw inputs are stored too: the test rewrites the directory from them."""
+    import contextlib
+    import io
+    out = {}
+    for tag in ("A", "B"):
+        frames, masks, dates, stations, cfg = dataset_case(tag)
+        tmp = tempfile.mkdtemp(prefix="gold_ds_")
+        write_dataset_case(tmp, frames, masks, dates, stations)
+        cfg["data"]["output_dir"] = os.path.join(tmp, "output")
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds = StreamflowDataset(os.path.join(tmp, "images"), os.path.join(tmp, "stations"), cfg, normalize=True)
+        out[f"{tag}_frames"] = frames
+        out[f"{tag}_mask_idx"] = np.array(sorted(masks), dtype=np.int64)
+        out[f"{tag}_masks"] = np.stack([masks[d] for d in sorted(masks)])
+        for n, (ts, lon, lat, run) in stations.items():
+            out[f"{tag}_st_{n}"] = np.stack([ts.astype(np.float64), lon, lat, run])
+        out[f"{tag}_order"] = np.array(list(ds.stations.keys()))
+        for k in ("image_mean", "image_std", "image_min", "image_max"):
+            out[f"{tag}_{k}"] = getattr(ds, k)
+        out[f"{tag}_runoff_stats"] = np.array([ds.runoff_mean, ds.runoff_std, ds.runoff_min, ds.runoff_max])
+        out[f"{tag}_n"] = np.array(len(ds))
+        for i in range(len(ds)):
+            smp = ds[i]
+            date = smp["date"]
+            out[f"{tag}_images{i}"] = smp["images"]
+            out[f"{tag}_target{i}"] = smp["output_image"]
+            out[f"{tag}_stations{i}"] = smp["stations"]
+            out[f"{tag}_pos{i}"] = smp["station_positions"]
+            out[f"{tag}_date{i}"] = np.array(date)
+            out[f"{tag}_names{i}"] = np.array([n for n, df in ds.stations.items()
+                                               if (df["timestamp"].astype(str) == date).any()])
+    save("dataset", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pixel", "encoder", "temporal", "decoder", "disc", "losses", "generator",
-                             "train", "evaluate"]
+                             "train", "evaluate", "dataset"]
     fns = {"pixel": gen_pixel, "encoder": gen_encoder, "temporal": gen_temporal, "decoder": gen_decoder,
            "disc": gen_disc, "losses": gen_losses, "generator": gen_generator, "train": gen_train,
-           "evaluate": gen_evaluate}
+           "evaluate": gen_evaluate, "dataset": gen_dataset}
     for w in which:
         fns[w]()

@@ -11,7 +11,7 @@ from oracle import streamflow_oracle as O
 torch.set_num_threads(8)
 
 
-# shapes of the reference modules' state_dicts, restated (SURVEY of src/model/*.py)
+# shapes of the reference modules' state_dicts, restated from src/model/*.py
 def encoder_shapes(cin, hd, prefix=""):
     s = {}
     ch = [cin, hd, hd * 2]
@@ -366,3 +366,29 @@ def test_evaluate_path():
     sm = res["station_metrics"]
     np.testing.assert_allclose([sm[k] for k in ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE")],
                                g["station_metrics"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_dataset_restatement(oracle, tag):
+    """Statistics and every sample of StreamflowDataset (masks, NaNs, threshold, resize, minmax
+    and z-score, ragged station rows).  Statistics to 1e-6 relative (the reference sums float32
+    per date with numpy's pairwise order, so does the restatement); samples to 1e-5 of the max."""
+    import goldgen as G
+    g = golden("dataset")
+    frames, masks, dates, stations, cfg = G.dataset_case(g, tag)
+    fr, mr = oracle.dataset_prepare(frames, masks, cfg["data"]["image_size"])
+    st = oracle.dataset_statistics(fr, mr, [stations[n][3] for n in G.DATASET_STATIONS])
+    for k in ("image_mean", "image_std", "image_min", "image_max"):
+        np.testing.assert_allclose(st[k], g[f"{tag}_{k}"], rtol=1e-6)
+    np.testing.assert_allclose(st["runoff"], g[f"{tag}_runoff_stats"], rtol=1e-12)
+    order = [str(n) for n in g[f"{tag}_order"]]
+    assert int(g[f"{tag}_n"]) == len(dates) - cfg["data"]["window_size"]
+    for i in range(int(g[f"{tag}_n"])):
+        s = oracle.dataset_sample(i, fr, mr, dates, stations, st, cfg, order)
+        assert s["date"] == str(g[f"{tag}_date{i}"])
+        ref_img, ref_t = g[f"{tag}_images{i}"], g[f"{tag}_target{i}"]
+        assert np.array_equal(np.isnan(s["output_image"]), np.isnan(ref_t))
+        close(np.nan_to_num(s["images"]), np.nan_to_num(ref_img), 1e-5)
+        close(np.nan_to_num(s["output_image"]), np.nan_to_num(ref_t), 1e-5)
+        assert np.array_equal(s["station_positions"], g[f"{tag}_pos{i}"])
+        np.testing.assert_allclose(s["stations"], g[f"{tag}_stations{i}"], rtol=1e-6)
