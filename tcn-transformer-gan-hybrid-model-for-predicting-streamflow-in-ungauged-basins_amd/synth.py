@@ -85,3 +85,28 @@ def make_batches(n_batches: int, batch: int, channels: int = 10, height: int = 2
                     "station_positions": [pos.clone() for _ in idx],
                     "stations": [torch.from_numpy(run_n[i + window].copy()) for i in idx]})
     return out
+
+
+def make_dataset_inputs(days: int, channels: int = 10, height: int = 200, width: int = 200, stations: int = 64,
+                        region=(100.0, 110.0, 25.0, 35.0), seed: int = 0):
+    """Raw (unnormalised) inputs of a dataset directory in memory: frames [days,C,H,W] float32,
+    date stems (YYYYMMDD from 2020-01-01, generate_dummy_data.py:205-206) and one DataFrame per
+    station (timestamp, lon, lat, runoff = 5x5 mean of channel 0 + 10 N(0,1), clipped at 0)."""
+    import datetime
+    import pandas as pd
+    raw = make_days(days, channels, height, width, seed)
+    rs = np.random.RandomState(seed)
+    lon = rs.uniform(region[0], region[1], stations)
+    lat = rs.uniform(region[2], region[3], stations)
+    px = np.clip(np.rint((lon - region[0]) / (region[1] - region[0]) * (width - 1)).astype(int), 0, width - 1)
+    py = np.clip(np.rint((region[3] - lat) / (region[3] - region[2]) * (height - 1)).astype(int), 0, height - 1)
+    start = datetime.date(2020, 1, 1)
+    dates = [(start + datetime.timedelta(days=d)).strftime("%Y%m%d") for d in range(days)]
+    frames = {}
+    for s in range(stations):
+        y0, y1 = max(0, py[s] - 2), min(height, py[s] + 3)
+        x0, x1 = max(0, px[s] - 2), min(width, px[s] + 3)
+        run = np.maximum(raw[:, 0, y0:y1, x0:x1].mean(axis=(1, 2)) + rs.randn(days) * 10.0, 0)
+        frames[f"station_{s:03d}"] = pd.DataFrame({"timestamp": [int(d) for d in dates], "lon": lon[s], "lat": lat[s],
+                                                   "runoff": run})
+    return raw, dates, frames
