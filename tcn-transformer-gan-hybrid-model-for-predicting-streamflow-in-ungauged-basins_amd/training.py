@@ -90,6 +90,25 @@ class FlatAdam:
         for p in self.params:
             p.grad = None
 
+    def state_by_name(self, module: nn.Module) -> Dict:
+        """Step count and both moments keyed by the module's parameter names (host copies)."""
+        names = {id(p): n for n, p in module.named_parameters()}
+        out = {"t": self.t, "exp_avg": {}, "exp_avg_sq": {}}
+        for p, (o, n) in zip(self.params, self.ranges):
+            out["exp_avg"][names[id(p)]] = self.m[o:o + n].view(p.shape).cpu().clone()
+            out["exp_avg_sq"][names[id(p)]] = self.v[o:o + n].view(p.shape).cpu().clone()
+        return out
+
+    def load_state_by_name(self, module: nn.Module, state: Dict):
+        names = {id(p): n for n, p in module.named_parameters()}
+        for p, (o, n) in zip(self.params, self.ranges):
+            k = names[id(p)]
+            if k not in state["exp_avg"] or tuple(state["exp_avg"][k].shape) != tuple(p.shape):
+                raise RuntimeError(f"optimiser state for {k} is missing or has the wrong shape")
+            self.m[o:o + n].copy_(state["exp_avg"][k].reshape(-1))
+            self.v[o:o + n].copy_(state["exp_avg_sq"][k].reshape(-1))
+        self.t = int(state["t"])
+
     def range_of(self, p: torch.Tensor):
         for q, r in zip(self.params, self.ranges):
             if q is p:
@@ -98,11 +117,14 @@ class FlatAdam:
 
 
 class Trainer:
-    def __init__(self, config: Dict, device: str = "cuda", distributed: Optional[bool] = None):
+    def __init__(self, config: Dict, device: str = "cuda", distributed: Optional[bool] = None,
+                 model_path: Optional[str] = None):
         self.config = config
         self.device = torch.device(device)
         mcfg, scfg = config.get("model", {}), config.get("system", {})
         self.model = StreamflowPredictionModel(config).to(self.device)
+        if model_path is not None:      # Trainer(config, model_path), src/train.py:49-51: a bare generator state_dict
+            self.model.load_state_dict(_host_load(model_path))
         self.loss_fn = CombinedLoss(config)
         lr = config.get("train", {}).get("lr", 1e-4)
         self.use_gan = bool(mcfg.get("use_gan", False))
@@ -252,3 +274,55 @@ class Trainer:
 
     def state_dict(self):
         return self.model.state_dict()
+
+    # ---- checkpoints ----------------------------------------------------------------------
+    def save_model(self, path: str):
+        """The reference's checkpoint (src/train.py:472-490): the generator's bare state_dict,
+        f32, reference keys.  Tensors are cloned to the host first: parameters are views into one
+        flat buffer, and torch.save of a view would write the whole buffer once per parameter."""
+        torch.save(_host_state(self.model), path)
+
+    def save_checkpoint(self, path: str):
+        """Resume file, a superset of the reference's: generator and discriminator state_dicts,
+        both Adam states (step, moments per parameter name), the batch counter that drives the
+        discriminator / accumulation schedule and the CPU generator state dropout seeds come from.
+        Plain tensors, ints and strings only (loads with weights_only=True)."""
+        ck = {"format": RESUME_FORMAT, "model": _host_state(self.model), "opt_g": self.opt_g.state_by_name(self.model),
+              "batch_idx": int(self.batch_idx), "cpu_rng_state": torch.get_rng_state()}
+        if self.use_gan:
+            ck["discriminator"] = _host_state(self.discriminator)
+            ck["opt_d"] = self.opt_d.state_by_name(self.discriminator)
+        torch.save(ck, path)
+
+    def load_checkpoint(self, path: str) -> str:
+        """Loads either file kind; returns "resume" or "model" (a bare generator state_dict as the
+        reference writes it: optimiser state, discriminator and counters keep their current values)."""
+        ck = _host_load(path)
+        if not (isinstance(ck, dict) and ck.get("format") == RESUME_FORMAT):
+            self.model.load_state_dict(ck)
+            return "model"
+        self.model.load_state_dict(ck["model"])
+        self.opt_g.load_state_by_name(self.model, ck["opt_g"])
+        if self.use_gan:
+            if "discriminator" not in ck:
+                raise RuntimeError("checkpoint was written without a discriminator but use_gan is set")
+            self.discriminator.load_state_dict(ck["discriminator"])
+            self.opt_d.load_state_by_name(self.discriminator, ck["opt_d"])
+        self.batch_idx = int(ck["batch_idx"])
+        torch.set_rng_state(ck["cpu_rng_state"])
+        self.opt_g.zero_grad()
+        if self.use_gan:
+            self.opt_d.zero_grad()
+        return "resume"
+
+
+RESUME_FORMAT = "sfhip-resume-1"
+
+
+def _host_state(module: nn.Module) -> Dict[str, torch.Tensor]:
+    return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+
+
+def _host_load(path: str):
+    """Checkpoints are read without unpickling code (tensors and plain containers only)."""
+    return torch.load(path, map_location="cpu", weights_only=True)

@@ -470,11 +470,24 @@ def gen_dataset():
     save("dataset", **out)
 
 
+def gen_ckpt():
+    """Key names, shapes and dtypes of the checkpoint the reference writes
+    (torch.save(model.state_dict()), src/train.py:472-490) for the train-test configurations."""
+    out = {}
+    for tag, temporal in (("tr", "Transformer"), ("lstm", "LSTM")):
+        m = StreamflowPredictionModel(model_cfg(16, temporal, 64, 3))
+        sd = m.state_dict()
+        out[f"{tag}_keys"] = np.array(list(sd.keys()))
+        out[f"{tag}_shapes"] = np.array([list(v.shape) + [-1] * (5 - v.dim()) for v in sd.values()])
+        out[f"{tag}_dtypes"] = np.array([str(v.dtype) for v in sd.values()])
+    save("checkpoint_keys", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pixel", "encoder", "temporal", "decoder", "disc", "losses", "generator",
-                             "train", "evaluate", "dataset"]
+                             "train", "evaluate", "dataset", "ckpt"]
     fns = {"pixel": gen_pixel, "encoder": gen_encoder, "temporal": gen_temporal, "decoder": gen_decoder,
            "disc": gen_disc, "losses": gen_losses, "generator": gen_generator, "train": gen_train,
-           "evaluate": gen_evaluate, "dataset": gen_dataset}
+           "evaluate": gen_evaluate, "dataset": gen_dataset, "ckpt": gen_ckpt}
     for w in which:
         fns[w]()
