@@ -349,6 +349,18 @@ int sf_dataset_transform(float* frames, float* target, const float* masks, const
 int sf_gather_frames(const float* src, long long src_stride, long long n_src,
                      const long long* rows, int n, long long n_elems, float* dst, void* stream);
 
+/* ---- evaluation metrics ---------------------------------------------------------------------- */
+/* Per-date image metrics of Evaluator.evaluate_dataset (src/evaluate.py:205-238) for a batch of
+ * predictions and targets, f32 [B,H,W] each, without a host sync.  out f64 [B,13] per date:
+ * sum (p-t)^2, sum |p-t|, sum p, sum t, sum p^2, sum t^2, sum p*t, min p, max p, min t, max t,
+ * the sum over all pixels of the SSIM map of calculate_ssim (src/evaluate.py:17-60: 11 x 11
+ * uniform window, scipy 'reflect' border, K1 = 0.01, K2 = 0.03, data range
+ * max(t.max - t.min, p.max - p.min) in float32), and that data range.  float64 sums in a fixed
+ * order.  ws: sf_date_image_metrics_workspace_bytes(B, H, W) bytes of device memory. */
+size_t sf_date_image_metrics_workspace_bytes(int B, int H, int W);
+int sf_date_image_metrics(const float* pred, const float* target, int B, int H, int W, double* out,
+                          void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,10 @@ target_*.npy / stations_eval.csv / evaluation_metrics.csv files).  What differs 
 the work: dates are independent, so they are forwarded in batches instead of one by one, and a
 list of dates can be sharded over ranks (one process per GPU); every shard returns order-free
 partial results that `merge_partials` combines into exactly the unsharded answer.  The metric
-arithmetic itself stays on the host in NumPy / SciPy, as in the reference.
+arithmetic stays on the host in NumPy / SciPy, as in the reference, for ordinary datasets; for a
+ResidentStreamflowDataset (frames already in HBM) the per-date image metrics come from
+sf_date_image_metrics on the device, consecutive dates share their encoded frames
+(StreamflowPredictionModel.forward_windows) and ranks take contiguous blocks of dates.
 """
 from __future__ import annotations
 
@@ -107,6 +110,37 @@ def merge_partials(partials: Sequence[Dict]) -> Dict:
     return out
 
 
+def resize_bilinear_device(target: torch.Tensor, OH: int, OW: int) -> torch.Tensor:
+    """resize_bilinear for a device tensor [B,1,h,w]; the result stays on the device."""
+    B, _, h, w = target.shape
+    Bp = ops.roundup(B, 4)
+    src = torch.zeros((1, h, w, Bp), device=target.device, dtype=torch.float32)
+    src[0, :, :, :B] = target.float()[:, 0].permute(1, 2, 0)
+    out = ops.bilinear_fwd(src, OH, OW, torch.float32)
+    return out[0, :, :, :B].permute(2, 0, 1).unsqueeze(1).contiguous()
+
+
+def per_date_from_moments(i: int, m: Sequence[float], npx: int):
+    """(index, SSIM, PSNR or None, correlation or None) of one date from a row of
+    sf_date_image_metrics, with the reference's special cases (src/evaluate.py:30-35,76-86,
+    218-230): zero data range, zero error, constant maps."""
+    sse, sae, sp, st, spp, stt, spt, pmin, pmax, tmin, tmax, ssim_sum, rng = [float(v) for v in m]
+    same = abs(pmin - tmin) <= 1e-8 + 1e-5 * abs(tmin)      # np.allclose of two constant maps
+    if rng == 0:
+        ssim, psnr = (1.0 if same else 0.0), (float("inf") if same else 0.0)
+    else:
+        ssim = ssim_sum / npx
+        mse = sse / npx
+        psnr = float("inf") if mse == 0 else float(20 * np.log10(rng / np.sqrt(mse)))
+    mp, mt = sp / npx, st / npx
+    vp, vt = max(spp / npx - mp * mp, 0.0), max(stt / npx - mt * mt, 0.0)
+    corr = None
+    if np.sqrt(vp) > 1e-10 and np.sqrt(vt) > 1e-10:
+        c = (spt / npx - mp * mt) / np.sqrt(vp * vt)
+        corr = None if np.isnan(c) else float(c)
+    return (i, float(ssim), None if np.isinf(psnr) else psnr, corr)
+
+
 def resize_bilinear(target: torch.Tensor, OH: int, OW: int, device) -> torch.Tensor:
     """Bilinear (align_corners=False) resize of [B,1,h,w] on the GPU (the kernel of
     F.interpolate's counterpart, sf_bilinear_fwd): the batch rides in the channel dimension of
@@ -168,6 +202,68 @@ class Evaluator:
             stations.append(((i, j), date, px, py, float(r), float(p2[y0:y1, x0:x1].mean())))
         return sse, sae, p.size, per_date, stations
 
+    def _station_rows(self, i: int, date: str, pos, runs, p2: np.ndarray, half: int):
+        rows = []
+        for j, (q, r) in enumerate(zip(pos, runs)):
+            px, py = int(q[0]), int(q[1])
+            y0, y1 = max(0, py - half), min(p2.shape[0], py + half + 1)
+            x0, x1 = max(0, px - half), min(p2.shape[1], px + half + 1)
+            rows.append(((i, j), date, px, py, float(r), float(p2[y0:y1, x0:x1].mean())))
+        return rows
+
+    def evaluate_partial_resident(self, dataset, indices: Sequence[int], batch_size: int = 16,
+                                  pred_dir: Optional[str] = None) -> Dict:
+        """evaluate_partial for a ResidentStreamflowDataset: windows are views of the resident
+        frames, a run of consecutive dates encodes each frame once, targets are resized and the
+        image metrics reduced on the device (sf_date_image_metrics); the host keeps the k x k
+        station means and the optional .npy files."""
+        part = _new_partial()
+        half = self.config.get("stations", {}).get("kernel_size", 3) // 2
+        idx = list(indices)
+        T = dataset.window_size
+        pending = None
+
+        def finish(job):
+            chunk, preds_h, tg_h, mom_h = job
+            npx = preds_h.shape[-1] * preds_h.shape[-2]
+            for k, i in enumerate(chunk):
+                m = mom_h[k]
+                part["sse"] += float(m[0])
+                part["sae"] += float(m[1])
+                part["npx"] += npx
+                part["per_date"].append(per_date_from_moments(i, m, npx))
+                o = i + T
+                date = dataset.dates[o]
+                p2 = preds_h[k, 0]
+                if pred_dir is not None:
+                    np.save(os.path.join(pred_dir, f"pred_{date}.npy"), p2)
+                    np.save(os.path.join(pred_dir, f"target_{date}.npy"), tg_h[k, 0])
+                sel = dataset.station_present[o]
+                part["stations"] += self._station_rows(i, date, dataset.station_pos[o][sel],
+                                                       dataset.station_runoff[o][sel], p2, half)
+
+        for b0 in range(0, len(idx), batch_size):
+            chunk = idx[b0:b0 + batch_size]
+            with torch.no_grad():
+                if all(b - a == 1 for a, b in zip(chunk, chunk[1:])):
+                    starts = torch.arange(len(chunk), device=self.device)
+                    preds = self.model.forward_windows(dataset.frames[chunk[0]:chunk[-1] + T], starts, T).float()
+                    tg = torch.stack([dataset._target_view(i + T) for i in chunk]) if dataset._own_targets \
+                        else dataset.frames[chunk[0] + T:chunk[-1] + T + 1, 0:1].contiguous()
+                else:
+                    b = dataset.batch(chunk)
+                    preds, tg = self.model(b["images"]).float(), b["output_image"]
+                if tg.shape != preds.shape:
+                    tg = resize_bilinear_device(tg, preds.shape[2], preds.shape[3])
+                mom = ops.date_image_metrics(preds.contiguous(), tg.contiguous())
+            # the previous chunk's host work runs while this chunk's kernels do
+            if pending is not None:
+                finish(pending)
+            pending = (chunk, preds.cpu().numpy(), tg.cpu().numpy() if pred_dir is not None else None, mom.cpu().numpy())
+        if pending is not None:
+            finish(pending)
+        return part
+
     def evaluate_partial(self, dataset: Sequence[Dict], indices: Sequence[int], batch_size: int = 16,
                          pred_dir: Optional[str] = None, workers: Optional[int] = None) -> Dict:
         """Metrics contributions of dataset[i] for i in indices (src/evaluate.py:186-268).  The
@@ -210,7 +306,14 @@ class Evaluator:
         if output_dir is not None:
             pred_dir = os.path.join(output_dir, "predictions")
             os.makedirs(pred_dir, exist_ok=True)
-        part = self.evaluate_partial(dataset, range(rank, len(dataset), world), batch_size, pred_dir)
+        from .dataset import ResidentStreamflowDataset
+        if isinstance(dataset, ResidentStreamflowDataset):
+            # contiguous blocks of dates per rank: neighbours share window - 1 encoded frames
+            n = len(dataset)
+            lo, hi = rank * n // world, (rank + 1) * n // world
+            part = self.evaluate_partial_resident(dataset, range(lo, hi), batch_size, pred_dir)
+        else:
+            part = self.evaluate_partial(dataset, range(rank, len(dataset), world), batch_size, pred_dir)
         parts: List[Dict] = [part]
         if world > 1 and dist.is_available() and dist.is_initialized():
             parts = [None] * dist.get_world_size()

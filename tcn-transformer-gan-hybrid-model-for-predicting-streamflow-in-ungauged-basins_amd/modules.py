@@ -250,6 +250,28 @@ class StreamflowPredictionModel(nn.Module):
                                SF.compute_dtype())
         return self.decoder(sp.view(B, oc, he, we))
 
+    def forward_windows(self, frames: torch.Tensor, starts: torch.Tensor, window: int) -> torch.Tensor:
+        """Eval-mode forward of the windows frames[s : s + window] for s in `starts` (device
+        int64 [B]) over frames [N,C,H,W]: every frame is encoded once however many windows share
+        it (adjacent evaluation dates share window - 1 of their frames).  Same result as
+        forward() on the stacked windows; not available in training mode, where BatchNorm uses
+        the statistics of the whole stacked batch."""
+        _need_cuda(frames, "StreamflowPredictionModel")
+        if self.training:
+            raise RuntimeError("forward_windows is an inference path: call model.eval() first")
+        N = frames.shape[0]
+        B = starts.numel()
+        encoded = self.cnn_encoder(frames).float().contiguous()
+        _, oc, he, we = encoded.shape
+        F = oc * he * we
+        rows = (starts.reshape(-1, 1) + torch.arange(window, device=starts.device).reshape(1, -1)).reshape(-1)
+        win = torch.empty((B * window, F), device=frames.device, dtype=torch.float32)
+        SF.ops.gather_frames(encoded, F, N, rows.contiguous(), F, win)
+        t_out = self.temporal_module(win.view(B, window, F))
+        sp = SF.LinearFn.apply(t_out, self.temporal_to_spatial.weight, self.temporal_to_spatial.bias,
+                               SF.compute_dtype())
+        return self.decoder(sp.view(B, oc, he, we))
+
     def get_num_parameters(self) -> int:
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 

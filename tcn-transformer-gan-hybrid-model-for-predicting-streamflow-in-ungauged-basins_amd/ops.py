@@ -58,6 +58,7 @@ def lib():
         L.sf_wgrad3x3_workspace_bytes.restype = ctypes.c_size_t
         L.sf_wgrad4x4s2_workspace_bytes.restype = ctypes.c_size_t
         L.sf_enc1_bwd_workspace_bytes.restype = ctypes.c_size_t
+        L.sf_date_image_metrics_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 
@@ -70,7 +71,7 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
            "sf_bce_logits", "sf_adam", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
-           "sf_gather_frames"]
+           "sf_gather_frames", "sf_date_image_metrics", "sf_date_image_metrics_workspace_bytes"]
 
 
 def _check(rc: int, who: str):
@@ -764,4 +765,21 @@ def gather_frames(src: torch.Tensor, src_stride: int, n_src: int, rows: torch.Te
     assert out.numel() == n * n_elems and src.numel() >= (n_src - 1) * src_stride + n_elems
     _check(lib().sf_gather_frames(_p(src), ctypes.c_longlong(src_stride), ctypes.c_longlong(n_src), _p(rows), n,
                                   ctypes.c_longlong(n_elems), _p(out), _stream()), "sf_gather_frames")
+    return out
+
+
+# ------------------------------------------------------------------------------ evaluation metrics
+def date_image_metrics(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """pred, target f32 [B,H,W] (or [B,1,H,W]) -> f64 [B,13] (see sf_date_image_metrics)."""
+    _dev(pred, target, dtypes=[torch.float32, torch.float32])
+    if pred.shape != target.shape:
+        raise RuntimeError("date_image_metrics: prediction and target shapes differ")
+    B, H, W = pred.shape[0], pred.shape[-2], pred.shape[-1]
+    if pred.numel() != B * H * W:
+        raise RuntimeError("date_image_metrics: single-channel maps expected")
+    nbytes = int(lib().sf_date_image_metrics_workspace_bytes(B, H, W))
+    ws = torch.empty(nbytes // 8, device=pred.device, dtype=torch.float64)
+    out = torch.empty((B, 13), device=pred.device, dtype=torch.float64)
+    _check(lib().sf_date_image_metrics(_p(pred), _p(target), B, H, W, _p(out), _p(ws), ctypes.c_size_t(nbytes),
+                                       _stream()), "sf_date_image_metrics")
     return out

@@ -145,3 +145,82 @@ def test_loader_feeds_a_train_step(sf, tmp_path):
         losses.append(float(o["total"].detach()))
         assert float(o["station"]) > 0
     assert len(losses) == len(shards[0]) and np.isfinite(losses).all() and not tr.saw_nan_or_inf()
+
+
+def test_resident_evaluation_against_reference_metrics(sf):
+    """Evaluator.evaluate_dataset over a ResidentStreamflowDataset (frames shared between adjacent
+    dates encoded once, image metrics from sf_date_image_metrics on the device, contiguous date
+    blocks per rank) against the metrics of the reference's own Evaluator (evaluate.npz) and
+    against the host SciPy / NumPy path on the same samples.  Stated tolerance 1e-4 relative
+    (float64 window sums here, float32 scipy filters in the reference); NSE to 3 decimals."""
+    from test_gpu_parity import load_gold
+    g = golden("evaluate")
+    n, T = int(g["n"]), int(g["images0"].shape[0])
+    C, S = int(g["images0"].shape[1]), int(g["images0"].shape[-1])
+    region = [90, 150, -15, 25]
+    # the fixture holds normalised samples: rebuild the date sequence they were cut from
+    frames = [g["images0"][d] for d in range(T)] + [g[f"images{i}"][T - 1] for i in range(1, n)]
+    last = np.zeros((C, S, S), np.float32)
+    last[0] = g[f"target{n - 1}"][0]
+    frames.append(last)
+    for i in range(n):                                    # targets are channel 0 of the next date
+        assert np.array_equal(frames[i + T][0], g[f"target{i}"][0])
+    dates = [f"202001{d + 1:02d}" for d in range(n + T)]
+    ns = int(g["pos0"].shape[0])
+    st = {}
+    for k in range(ns):
+        px, py = float(g["pos0"][k, 0]), float(g["pos0"][k, 1])
+        run = [0.0] * T + [float(g[f"stations{i}"][k]) for i in range(n)]
+        st[f"s{k}"] = pd.DataFrame({"timestamp": [int(d) for d in dates],
+                                    "lon": region[0] + px / (S - 1) * (region[1] - region[0]),
+                                    "lat": region[3] - py / (S - 1) * (region[3] - region[2]), "runoff": run})
+    cfg = {"data": {"upscale_factor": 2, "image_size": [S, S], "window_size": T, "region": region, "flow_threshold": 0.0},
+           "model": {"input_channels": C, "hidden_dim": 16, "num_layers": 2, "temporal_module": "LSTM"},
+           "stations": {"kernel_size": 3}}
+    ds = sf.ResidentStreamflowDataset.from_arrays(frames, dates, st, cfg, normalize=False)
+    for i in range(n):
+        assert np.array_equal(ds[i]["images"].cpu().numpy(), g[f"images{i}"])
+        assert np.array_equal(ds[i]["station_positions"].numpy(), g[f"pos{i}"])
+    m = sf.StreamflowPredictionModel(cfg).to("cuda")
+    load_gold(m, "eval_g")
+    ev = sf.Evaluator(cfg, model=m)
+    keys, skeys = ("RMSE", "MAE", "SSIM", "PSNR", "Correlation"), ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE")
+    host = ev.evaluate_dataset([ds[i] for i in range(n)], batch_size=2)      # list dataset: host metrics path
+    for bs in (1, 3, 16):
+        res = ev.evaluate_dataset(ds, batch_size=bs)
+        np.testing.assert_allclose([res[k] for k in keys], g["metrics"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose([res["station_metrics"][k] for k in skeys], g["station_metrics"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose([res[k] for k in keys], [host[k] for k in keys], rtol=1e-4, atol=1e-5)
+    parts = [ev.evaluate_dataset(ds, batch_size=2, shard=(r, 2))["partial"] for r in (0, 1)]
+    assert [len(p["per_date"]) for p in parts] == [n // 2, n - n // 2]
+    res = sf.merge_partials(parts)
+    np.testing.assert_allclose([res[k] for k in keys], g["metrics"], rtol=1e-4, atol=1e-5)
+    assert round(res["station_metrics"]["NSE"], 3) == round(float(g["station_metrics"][3]), 3)
+
+
+def test_date_image_metrics_kernel_against_scipy(sf):
+    """sf_date_image_metrics on odd-sized maps (partial tiles, maps narrower than the window's
+    halo, a constant pair) against scipy's uniform_filter SSIM and NumPy moments."""
+    import importlib
+    E = importlib.import_module(sf.__name__ + ".evaluation")
+    rs = np.random.RandomState(4)
+    for (B, H, W) in [(3, 400, 400), (2, 37, 70), (2, 3, 9), (1, 1, 1)]:
+        p = rs.standard_normal((B, H, W)).astype(np.float32)
+        t = (0.6 * p + 0.4 * rs.standard_normal((B, H, W))).astype(np.float32)
+        if B > 1:
+            p[1], t[1] = 2.5, 2.5                                     # constant and equal: zero data range
+        out = sf.ops.date_image_metrics(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+        for b in range(B):
+            pd64, td64 = p[b].astype(np.float64), t[b].astype(np.float64)
+            want = [((pd64 - td64) ** 2).sum(), np.abs(pd64 - td64).sum(), pd64.sum(), td64.sum(), (pd64 ** 2).sum(),
+                    (td64 ** 2).sum(), (pd64 * td64).sum(), p[b].min(), p[b].max(), t[b].min(), t[b].max()]
+            np.testing.assert_allclose(out[b, :11], want, rtol=1e-12, atol=1e-12)
+            i, ssim, psnr, corr = E.per_date_from_moments(7, out[b], H * W)
+            assert i == 7
+            assert abs(ssim - E.calculate_ssim(p[b], t[b])) < 1e-4
+            ref_psnr = E.calculate_psnr(p[b], t[b])
+            assert (psnr is None and np.isinf(ref_psnr)) or abs(psnr - ref_psnr) < 1e-3
+            if p[b].std() > 1e-10 and t[b].std() > 1e-10:
+                assert abs(corr - np.corrcoef(p[b].reshape(-1), t[b].reshape(-1))[0, 1]) < 1e-6
+            else:
+                assert corr is None
