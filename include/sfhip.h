@@ -299,8 +299,9 @@ int sf_lonlat_to_pixel(const double* lon, const double* lat, int n, double lon_m
  * sizes differ); stations packed: pos int32 [S][2] (x=column, y=row), runoff f32 [S],
  * sample offsets int32 [B+1].  metric 0 = MSE, 1 = MAE (image_metric / station_metric).
  * losses[0..2] = total, image, station.  dpred f32 [B,1,H,W] = d total / d pred.
- * ws: 4 doubles (zeroed here).
+ * ws: SF_LOSS_WS_DOUBLES doubles of device scratch (per-block partial sums; no zeroing needed).
  */
+#define SF_LOSS_WS_DOUBLES 4096
 int sf_image_station_loss(const float* pred, const float* target, const int* pos,
                           const float* runoff, const int* offsets, int S, int B, int H, int W,
                           int TH, int TW, int image_metric, float nonzero_weight,

@@ -54,86 +54,254 @@ __device__ __forceinline__ float station_mean(const LossArgs& a, int b, int px, 
     return n > 0 ? s / (float)n : 0.f;
 }
 
+// sample whose station range [offsets[b], offsets[b+1]) holds s (empty samples are skipped)
 __device__ __forceinline__ int sample_of(const int* offsets, int B, int s) {
-    int b = 0;
-    while (b + 1 < B && offsets[b + 1] <= s) ++b;
-    return b;
+    int lo = 0, hi = B - 1;            // invariant: offsets[lo] <= s, answer in [lo, hi]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (offsets[mid] <= s) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
-// pass 1: ws[0] = sum w, ws[1] = sum w*pixel_loss, ws[2] = sum station loss terms, ws[3] = #stations
-__global__ void loss_reduce_kernel(LossArgs a, double* __restrict__ ws, int pixel_blocks) {
-    __shared__ double smd[8];
-    if ((int)blockIdx.x < pixel_blocks) {
-        const long long total = (long long)a.B * a.H * a.W;
-        double sw = 0.0, sl = 0.0;
-        for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)pixel_blocks * NT) {
-            const int x = (int)(o % a.W);
-            const long long r = o / a.W;
-            const int y = (int)(r % a.H);
-            const int b = (int)(r / a.H);
-            const float t = target_at(a, b, y, x);
-            const float w = 1.0f + (a.nonzero_weight - 1.0f) * (fabsf(t) > a.zero_threshold ? 1.0f : 0.0f);
-            const float d = a.pred[o] - t;
-            const float pl = a.image_metric == 0 ? d * d : fabsf(d);
-            sw += (double)w;
-            sl += (double)(pl * w);
+// Workspace layout (doubles): per-block partial sums, written in full by every call (nothing to
+// zero) and folded in a fixed order, so the losses are bit-reproducible.
+constexpr int LP = 1024;                  // max pixel blocks of either pass
+constexpr int LS = 1024;                  // max station blocks
+constexpr int WS_W = 0;                   // [LP] sum of pixel weights (pass 1)
+constexpr int WS_L = LP;                  // [LP] sum of weight * pixel loss (pass 2)
+constexpr int WS_ST = 2 * LP;             // [LS] station loss terms (pass 2)
+constexpr int WS_SC = 2 * LP + LS;        // [LS] stations with a non-empty window (pass 1)
+static_assert(2 * LP + 2 * LS <= SF_LOSS_WS_DOUBLES, "loss workspace layout");
+
+__device__ __forceinline__ float pixel_weight(const LossArgs& a, float t) {
+    return 1.0f + (a.nonzero_weight - 1.0f) * (fabsf(t) > a.zero_threshold ? 1.0f : 0.0f);
+}
+
+// sum of n partials (n <= 1024) by one 256-thread block, fixed order; valid in every thread
+__device__ __forceinline__ double fold_partials(const double* __restrict__ part, int n, double* sm) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += NT) v += part[i];
+    return block_sum_256_d(v, sm);
+}
+
+// The pixel passes walk the prediction grid by rows: a wave takes rows (b, y) = wave, wave + nwaves,
+// ... and its lanes take V consecutive pixels each, so the horizontal resize taps of a lane are
+// computed once and kept for all its rows, the vertical taps once per row, and all index
+// arithmetic is 32-bit.
+template <int V> struct ColTaps { int i0[V], i1[V]; float l0[V], l1[V]; };
+
+template <int V>
+__device__ __forceinline__ ColTaps<V> col_taps(const LossArgs& a, int x) {
+    ColTaps<V> c;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const AxisW ax = axis_w(x + e, a.TW, a.W);
+        c.i0[e] = ax.i0; c.i1[e] = ax.i1; c.l0[e] = ax.l0; c.l1[e] = ax.l1;
+    }
+    return c;
+}
+
+// One pixel pass of a block.  MAIN = false: returns the block's part of sum w.  MAIN = true:
+// returns its part of sum w * pixel loss and writes the image gradient gscale * w * d(loss)/d(pred).
+// A wave works on two adjacent prediction rows at a time, its lanes on V consecutive pixels of
+// up to two column groups: 4 items whose loads are all issued first, from clamped (always valid)
+// addresses; results of items outside the grid are dropped afterwards -- no load sits behind a
+// branch.  When the target is smaller than the prediction and its rows fit (TW <= SROW), the
+// wave first copies the four target rows the two prediction rows interpolate between into its
+// own LDS slice with coalesced loads and takes the resize taps from there: per-lane gathers
+// from global memory cost an instruction per tap and bound the pass otherwise.
+constexpr int SROW = 512;
+template <int V, bool MAIN>
+__device__ __forceinline__ float pixel_pass(const LossArgs& a, int pixel_blocks, float gscale, float* __restrict__ dpred) {
+    __shared__ float srow[NT / 64][4][SROW];
+    const bool same = a.TH == a.H && a.TW == a.W;
+    const bool staged = !same && a.TW <= SROW;
+    const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6, wave = (int)blockIdx.x * (NT / 64) + wl;
+    const int nwaves = pixel_blocks * (NT / 64), rows = a.B * a.H, wv = a.W / V;
+    const int npairs = (rows + 1) >> 1;
+    float acc = 0.f;
+    for (int xb = 0; xb < wv; xb += 128) {
+        int xv[2];
+        bool xin[2];
+        ColTaps<V> c[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            xv[i] = xb + 64 * i + lane;
+            xin[i] = xv[i] < wv;
+            if (!xin[i]) xv[i] = wv - 1;
+            c[i] = col_taps<V>(a, xv[i] * V);
         }
-        sw = block_sum_256_d(sw, smd);
-        sl = block_sum_256_d(sl, smd + 4);
-        if (threadIdx.x == 0) { unsafeAtomicAdd(&ws[0], sw); unsafeAtomicAdd(&ws[1], sl); }
+        for (int pr = wave; pr < npairs; pr += nwaves) {
+            float t[4][V], pv[4][V];
+            bool ok[4];
+            size_t off[4];
+            AxisW ay[2];
+            const float* tp[2];
+            int yy[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rr = 2 * pr + j;
+                const int r = rr < rows ? rr : rows - 1;
+                const int b = r / a.H;
+                yy[j] = r - b * a.H;
+                tp[j] = a.target + (size_t)b * a.TH * a.TW;
+                ay[j] = axis_w(yy[j], a.TH, a.H);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int u = 2 * j + i;
+                    ok[u] = rr < rows && xin[i];
+                    off[u] = (size_t)r * a.W + xv[i] * V;
+                    if (MAIN) {
+                        if (V == 4) {
+                            const float4 v = *reinterpret_cast<const float4*>(a.pred + off[u]);
+                            pv[u][0] = v.x; pv[u][1] = v.y; pv[u][2] = v.z; pv[u][3] = v.w;
+                        } else {
+                            pv[u][0] = a.pred[off[u]];
+                        }
+                    }
+                }
+            }
+            if (staged) {
+                // rows ay[j].i0 / ay[j].i1 of the target -> srow[wl][2j], srow[wl][2j+1]
+                __builtin_amdgcn_wave_barrier();          // the previous pair's reads are done (same wave, in order)
+                for (int x = lane; x < a.TW; x += 64) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = tp[q >> 1][((q & 1) ? ay[q >> 1].i1 : ay[q >> 1].i0) * a.TW + x];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) srow[wl][q][x] = v[q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int u = 2 * j + i;
+                    if (same) {
+                        if (V == 4) {
+                            const float4 v = *reinterpret_cast<const float4*>(tp[j] + (size_t)yy[j] * a.W + xv[i] * V);
+                            t[u][0] = v.x; t[u][1] = v.y; t[u][2] = v.z; t[u][3] = v.w;
+                        } else {
+                            t[u][0] = tp[j][(size_t)yy[j] * a.W + xv[i]];
+                        }
+                    } else {
+                        // same expression as F.interpolate's bilinear kernel (align_corners=False)
+                        auto taps = [&](const auto* q0, const auto* q1) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e)
+                                t[u][e] = ay[j].l0 * (c[i].l0[e] * q0[c[i].i0[e]] + c[i].l1[e] * q0[c[i].i1[e]]) +
+                                          ay[j].l1 * (c[i].l0[e] * q1[c[i].i0[e]] + c[i].l1[e] * q1[c[i].i1[e]]);
+                        };
+                        if (staged) taps(&srow[wl][2 * j][0], &srow[wl][2 * j + 1][0]);   // LDS addresses stay LDS addresses
+                        else taps(tp[j] + ay[j].i0 * a.TW, tp[j] + ay[j].i1 * a.TW);
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float g[V];
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float w = pixel_weight(a, t[u][e]);
+                    if (MAIN) {
+                        const float d = pv[u][e] - t[u][e];
+                        part += (a.image_metric == 0 ? d * d : fabsf(d)) * w;
+                        g[e] = gscale * w * (a.image_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+                    } else {
+                        part += w;
+                    }
+                }
+                acc += ok[u] ? part : 0.f;
+                if (MAIN && ok[u]) {
+                    if (V == 4) *reinterpret_cast<float4*>(dpred + off[u]) = make_float4(g[0], g[1], g[2], g[3]);
+                    else dpred[off[u]] = g[0];
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+// pass 1 (needs the target and the station positions only): the weight sum the image gradient is
+// divided by, and the number of stations that count.  Blocks [0, pixel_blocks) walk the
+// prediction grid, the others count stations.
+template <int V>
+__global__ __launch_bounds__(NT) void loss_weights_kernel(LossArgs a, double* __restrict__ ws, int pixel_blocks) {
+    __shared__ double smd[4];
+    if ((int)blockIdx.x < pixel_blocks) {
+        const double s = block_sum_256_d((double)pixel_pass<V, false>(a, pixel_blocks, 0.f, nullptr), smd);
+        if (threadIdx.x == 0) ws[WS_W + blockIdx.x] = s;
     } else {
+        const int sb = (int)blockIdx.x - pixel_blocks, nsb = (int)gridDim.x - pixel_blocks;
+        const int half = a.ksize / 2;
+        double tc = 0.0;
+        for (int s = sb * NT + threadIdx.x; s < a.S; s += nsb * NT) {
+            const int px = a.pos[2 * s], py = a.pos[2 * s + 1];
+            const int wh = min(a.H, py + half + 1) - max(0, py - half), ww = min(a.W, px + half + 1) - max(0, px - half);
+            tc += (wh > 0 && ww > 0) ? 1.0 : 0.0;
+        }
+        tc = block_sum_256_d(tc, smd);
+        if (threadIdx.x == 0) ws[WS_SC + sb] = tc;
+    }
+}
+
+// pass 2: one read of pred and target; the image gradient (already divided by the weight sum)
+// goes to dpred, the block's sum of weighted pixel losses to the workspace; the station blocks
+// gather their window means.
+template <int V>
+__global__ __launch_bounds__(NT) void loss_main_kernel(LossArgs a, double* __restrict__ ws, float* __restrict__ dpred,
+                                                       int pixel_blocks, int pixel_blocks1) {
+    __shared__ double smd[4];
+    if ((int)blockIdx.x < pixel_blocks) {
+        const float inv_sw = (float)(1.0 / fold_partials(ws + WS_W, pixel_blocks1, smd));
+        const double s = block_sum_256_d((double)pixel_pass<V, true>(a, pixel_blocks, a.image_weight * inv_sw, dpred), smd);
+        if (threadIdx.x == 0) ws[WS_L + blockIdx.x] = s;
+    } else {
+        const int sb = (int)blockIdx.x - pixel_blocks, nsb = (int)gridDim.x - pixel_blocks;
         const int lane = threadIdx.x & 63;
-        const int wave = ((int)blockIdx.x - pixel_blocks) * (NT / 64) + (threadIdx.x >> 6);
-        const int nwaves = ((int)gridDim.x - pixel_blocks) * (NT / 64);
-        double tl = 0.0, tc = 0.0;
-        for (int s = wave; s < a.S; s += nwaves) {
+        double tl = 0.0;
+        for (int s = sb * (NT / 64) + (threadIdx.x >> 6); s < a.S; s += nsb * (NT / 64)) {
             const int b = sample_of(a.offsets, a.B, s);
             int n, x0, y0, ww;
             const float m = station_mean(a, b, a.pos[2 * s], a.pos[2 * s + 1], lane, &n, &x0, &y0, &ww);
-            if (n > 0) {
+            if (n > 0 && lane == 0) {
                 const float d = m - a.runoff[s];
                 tl += (double)(a.station_metric == 0 ? d * d : fabsf(d));
-                tc += 1.0;
             }
         }
-        if (lane == 0 && tc > 0.0) { unsafeAtomicAdd(&ws[2], tl); unsafeAtomicAdd(&ws[3], tc); }
+        tl = block_sum_256_d(tl, smd);
+        if (threadIdx.x == 0) ws[WS_ST + sb] = tl;
     }
 }
 
-// pass 2: dpred = image_weight * d(image loss); thread 0 of block 0 writes the three losses
-__global__ void loss_image_grad_kernel(LossArgs a, const double* __restrict__ ws, float* __restrict__ losses,
-                                       float* __restrict__ dpred) {
-    const double sw = ws[0];
-    const float inv_sw = (float)(1.0 / sw);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const float img = (float)(ws[1] / sw);
-        const float stn = ws[3] > 0.0 ? (float)(ws[2] / ws[3]) : 0.f;
-        losses[1] = img;
-        losses[2] = stn;
-        losses[0] = a.image_weight * img + a.station_weight * stn;
+// pass 3: block 0 folds the partials into the three losses; every block scatters the station
+// gradient of its stations (windows may overlap -> atomics) onto the image gradient.
+__global__ __launch_bounds__(NT) void loss_finish_kernel(LossArgs a, const double* __restrict__ ws,
+                                                         float* __restrict__ losses, float* __restrict__ dpred,
+                                                         int pixel_blocks1, int pixel_blocks2, int count_blocks,
+                                                         int station_blocks) {
+    __shared__ double smd[4];
+    const double cnt_d = fold_partials(ws + WS_SC, count_blocks, smd);
+    if (blockIdx.x == 0) {
+        const double sw = fold_partials(ws + WS_W, pixel_blocks1, smd);
+        const double sl = fold_partials(ws + WS_L, pixel_blocks2, smd);
+        const double tl = fold_partials(ws + WS_ST, station_blocks, smd);
+        if (threadIdx.x == 0) {
+            const float img = (float)(sl / sw);
+            const float stn = cnt_d > 0.0 ? (float)(tl / cnt_d) : 0.f;
+            losses[1] = img;
+            losses[2] = stn;
+            losses[0] = a.image_weight * img + a.station_weight * stn;
+        }
     }
-    const long long total = (long long)a.B * a.H * a.W;
-    for (long long o = blockIdx.x * (long long)NT + threadIdx.x; o < total; o += (long long)gridDim.x * NT) {
-        const int x = (int)(o % a.W);
-        const long long r = o / a.W;
-        const int y = (int)(r % a.H);
-        const int b = (int)(r / a.H);
-        const float t = target_at(a, b, y, x);
-        const float w = 1.0f + (a.nonzero_weight - 1.0f) * (fabsf(t) > a.zero_threshold ? 1.0f : 0.0f);
-        const float d = a.pred[o] - t;
-        const float g = a.image_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        dpred[o] = a.image_weight * g * w * inv_sw;
-    }
-}
-
-// pass 3: scatter the station gradient (windows may overlap -> atomics)
-__global__ void loss_station_grad_kernel(LossArgs a, const double* __restrict__ ws, float* __restrict__ dpred) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (int)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    const int nwaves = (int)gridDim.x * (NT / 64);
-    const float cnt = (float)ws[3];
+    const float cnt = (float)cnt_d;
     if (cnt <= 0.f) return;
-    for (int s = wave; s < a.S; s += nwaves) {
+    const int lane = threadIdx.x & 63;
+    for (int s = (int)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); s < a.S; s += (int)gridDim.x * (NT / 64)) {
         const int b = sample_of(a.offsets, a.B, s);
         int n, x0, y0, ww;
         const float m = station_mean(a, b, a.pos[2 * s], a.pos[2 * s + 1], lane, &n, &x0, &y0, &ww);
@@ -231,13 +399,26 @@ extern "C" int sf_image_station_loss(const float* pred, const float* target, con
     a.S = S; a.B = B; a.H = H; a.W = W; a.TH = TH; a.TW = TW; a.image_metric = image_metric; a.ksize = ksize;
     a.station_metric = station_metric; a.nonzero_weight = nonzero_weight; a.zero_threshold = zero_threshold;
     a.image_weight = image_weight; a.station_weight = station_weight;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 4, s) != hipSuccess) { sf_set_error("sf_image_station_loss: memset failed"); return SF_ELAUNCH; }
     const long long total = (long long)B * H * W;
-    int pblocks = (int)((total + NT * 8 - 1) / (NT * 8)); if (pblocks > 2048) pblocks = 2048; if (pblocks < 1) pblocks = 1;
-    int sblocks = S > 0 ? (S + 3) / 4 : 0; if (sblocks > 1024) sblocks = 1024;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(pblocks + sblocks), dim3(NT), 0, s, a, ws, pblocks);
-    hipLaunchKernelGGL(loss_image_grad_kernel, dim3(pblocks), dim3(NT), 0, s, a, ws, losses, dpred);
-    if (sblocks > 0) hipLaunchKernelGGL(loss_station_grad_kernel, dim3(sblocks), dim3(NT), 0, s, a, ws, dpred);
+    const bool vec = W % 4 == 0 && ((uintptr_t)pred | (uintptr_t)dpred | (uintptr_t)target) % 16 == 0 &&
+                     (TW % 4 == 0 || TH != H || TW != W);
+    SF_REQUIRE((long long)B * H < 0x7fffffffLL && total < (1LL << 40), "sf_image_station_loss: batch too large");
+    // a wave per row at a time: pass 1 only evaluates the target (several rows per wave), pass 2
+    // streams pred / dpred
+    const long long rows = (long long)B * H;
+    int p1 = (int)((rows + 7) / 8); if (p1 > LP) p1 = LP; if (p1 < 1) p1 = 1;
+    int p2 = (int)((rows + 7) / 8); if (p2 > LP) p2 = LP; if (p2 < 1) p2 = 1;
+    int sb1 = (S + NT - 1) / NT; if (sb1 > LS) sb1 = LS; if (sb1 < 1) sb1 = 1;
+    int sb2 = (S + 3) / 4; if (sb2 > LS) sb2 = LS; if (sb2 < 1) sb2 = 1;
+    // the station slabs are written by sb2 (pass 2) and sb1 (pass 1) blocks and folded over exactly those
+    if (vec) {
+        hipLaunchKernelGGL(loss_weights_kernel<4>, dim3(p1 + sb1), dim3(NT), 0, s, a, ws, p1);
+        hipLaunchKernelGGL(loss_main_kernel<4>, dim3(p2 + sb2), dim3(NT), 0, s, a, ws, dpred, p2, p1);
+    } else {
+        hipLaunchKernelGGL(loss_weights_kernel<1>, dim3(p1 + sb1), dim3(NT), 0, s, a, ws, p1);
+        hipLaunchKernelGGL(loss_main_kernel<1>, dim3(p2 + sb2), dim3(NT), 0, s, a, ws, dpred, p2, p1);
+    }
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(sb2), dim3(NT), 0, s, a, ws, losses, dpred, p1, p2, sb1, sb2);
     SF_LAUNCH_CHECK("sf_image_station_loss");
     return SF_OK;
 }

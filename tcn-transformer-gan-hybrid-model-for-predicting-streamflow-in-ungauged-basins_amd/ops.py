@@ -126,6 +126,7 @@ FORCE_GENERIC_CONV = False
 
 # Launch timing for the benchmark's roofline line: tags listed in TIMED get a HIP event pair
 # recorded on the launch stream around each sf_gemm call carrying that tag.
+LOSS_WS_DOUBLES = 4096  # SF_LOSS_WS_DOUBLES of include/sfhip.h
 TIMED: dict = {}
 
 
@@ -703,7 +704,7 @@ def image_station_loss(pred, target, pos, runoff, offsets, S, image_metric, nonz
     TH, TW = target.shape[-2], target.shape[-1]
     losses = torch.empty(3, device=pred.device, dtype=torch.float32)
     dpred = torch.empty_like(pred)
-    ws = torch.empty(4, device=pred.device, dtype=torch.float64)
+    ws = torch.empty(LOSS_WS_DOUBLES, device=pred.device, dtype=torch.float64)
     _check(lib().sf_image_station_loss(_p(pred), _p(target), _p(pos), _p(runoff), _p(offsets), S, B, H, W, TH, TW,
                                        image_metric, _c_f(nonzero_weight), _c_f(zero_threshold), ksize, station_metric,
                                        _c_f(image_weight), _c_f(station_weight), _p(losses), _p(dpred), _p(ws),
