@@ -298,7 +298,10 @@ int sf_lonlat_to_pixel(const double* lon, const double* lat, int n, double lon_m
  * pred f32 [B,1,H,W]; target f32 [B,1,TH,TW] (bilinearly resized to HxW on the fly when the
  * sizes differ); stations packed: pos int32 [S][2] (x=column, y=row), runoff f32 [S],
  * sample offsets int32 [B+1].  metric 0 = MSE, 1 = MAE (image_metric / station_metric).
- * losses[0..2] = total, image, station.  dpred f32 [B,1,H,W] = d total / d pred.
+ * losses f32 [4]: total, image, station, and 1 / (sum of the image loss's pixel weights).
+ * dpred f32 [B,1,H,W]: d total / d pred = dpred * losses[3].  The weight sum is only complete
+ * when the single pass over pred has finished, so the division is left to the caller, who
+ * multiplies by the upstream gradient anyway (one scalar product, then one pass).
  * ws: SF_LOSS_WS_DOUBLES doubles of device scratch (per-block partial sums; no zeroing needed).
  */
 #define SF_LOSS_WS_DOUBLES 4096

@@ -66,12 +66,12 @@ __device__ __forceinline__ int sample_of(const int* offsets, int B, int s) {
 
 // Workspace layout (doubles): per-block partial sums, written in full by every call (nothing to
 // zero) and folded in a fixed order, so the losses are bit-reproducible.
-constexpr int LP = 1024;                  // max pixel blocks of either pass
+constexpr int LP = 1024;                  // max pixel blocks
 constexpr int LS = 1024;                  // max station blocks
-constexpr int WS_W = 0;                   // [LP] sum of pixel weights (pass 1)
-constexpr int WS_L = LP;                  // [LP] sum of weight * pixel loss (pass 2)
-constexpr int WS_ST = 2 * LP;             // [LS] station loss terms (pass 2)
-constexpr int WS_SC = 2 * LP + LS;        // [LS] stations with a non-empty window (pass 1)
+constexpr int WS_W = 0;                   // [LP] sum of pixel weights
+constexpr int WS_L = LP;                  // [LP] sum of weight * pixel loss
+constexpr int WS_ST = 2 * LP;             // [LS] station loss terms
+constexpr int WS_SC = 2 * LP + LS;        // [LS] stations with a non-empty window
 static_assert(2 * LP + 2 * LS <= SF_LOSS_WS_DOUBLES, "loss workspace layout");
 
 __device__ __forceinline__ float pixel_weight(const LossArgs& a, float t) {
@@ -102,8 +102,10 @@ __device__ __forceinline__ ColTaps<V> col_taps(const LossArgs& a, int x) {
     return c;
 }
 
-// One pixel pass of a block.  MAIN = false: returns the block's part of sum w.  MAIN = true:
-// returns its part of sum w * pixel loss and writes the image gradient gscale * w * d(loss)/d(pred).
+// The pixel pass of a block: adds its part of sum w to accw and of sum w * pixel loss to accl, and
+// writes the image gradient BEFORE the division by the weight sum, gscale * w * d(loss)/d(pred):
+// the sum is only known once every block is done, so 1 / sum w is handed to the caller
+// (losses[3]) and multiplied in together with the upstream gradient.
 // A wave works on two adjacent prediction rows at a time, its lanes on V consecutive pixels of
 // up to two column groups: 4 items whose loads are all issued first, from clamped (always valid)
 // addresses; results of items outside the grid are dropped afterwards -- no load sits behind a
@@ -112,15 +114,15 @@ __device__ __forceinline__ ColTaps<V> col_taps(const LossArgs& a, int x) {
 // own LDS slice with coalesced loads and takes the resize taps from there: per-lane gathers
 // from global memory cost an instruction per tap and bound the pass otherwise.
 constexpr int SROW = 512;
-template <int V, bool MAIN>
-__device__ __forceinline__ float pixel_pass(const LossArgs& a, int pixel_blocks, float gscale, float* __restrict__ dpred) {
+template <int V>
+__device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, float gscale, float* __restrict__ dpred,
+                                           float& accw, float& accl) {
     __shared__ float srow[NT / 64][4][SROW];
     const bool same = a.TH == a.H && a.TW == a.W;
     const bool staged = !same && a.TW <= SROW;
     const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6, wave = (int)blockIdx.x * (NT / 64) + wl;
     const int nwaves = pixel_blocks * (NT / 64), rows = a.B * a.H, wv = a.W / V;
     const int npairs = (rows + 1) >> 1;
-    float acc = 0.f;
     for (int xb = 0; xb < wv; xb += 128) {
         int xv[2];
         bool xin[2];
@@ -152,13 +154,11 @@ __device__ __forceinline__ float pixel_pass(const LossArgs& a, int pixel_blocks,
                     const int u = 2 * j + i;
                     ok[u] = rr < rows && xin[i];
                     off[u] = (size_t)r * a.W + xv[i] * V;
-                    if (MAIN) {
-                        if (V == 4) {
-                            const float4 v = *reinterpret_cast<const float4*>(a.pred + off[u]);
-                            pv[u][0] = v.x; pv[u][1] = v.y; pv[u][2] = v.z; pv[u][3] = v.w;
-                        } else {
-                            pv[u][0] = a.pred[off[u]];
-                        }
+                    if (V == 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(a.pred + off[u]);
+                        pv[u][0] = v.x; pv[u][1] = v.y; pv[u][2] = v.z; pv[u][3] = v.w;
+                    } else {
+                        pv[u][0] = a.pred[off[u]];
                     }
                 }
             }
@@ -203,67 +203,42 @@ __device__ __forceinline__ float pixel_pass(const LossArgs& a, int pixel_blocks,
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float g[V];
-                float part = 0.f;
+                float pw = 0.f, pl = 0.f;
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     const float w = pixel_weight(a, t[u][e]);
-                    if (MAIN) {
-                        const float d = pv[u][e] - t[u][e];
-                        part += (a.image_metric == 0 ? d * d : fabsf(d)) * w;
-                        g[e] = gscale * w * (a.image_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
-                    } else {
-                        part += w;
-                    }
+                    const float d = pv[u][e] - t[u][e];
+                    pw += w;
+                    pl += (a.image_metric == 0 ? d * d : fabsf(d)) * w;
+                    g[e] = gscale * w * (a.image_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
                 }
-                acc += ok[u] ? part : 0.f;
-                if (MAIN && ok[u]) {
+                accw += ok[u] ? pw : 0.f;
+                accl += ok[u] ? pl : 0.f;
+                if (ok[u]) {
                     if (V == 4) *reinterpret_cast<float4*>(dpred + off[u]) = make_float4(g[0], g[1], g[2], g[3]);
                     else dpred[off[u]] = g[0];
                 }
             }
         }
     }
-    return acc;
 }
 
-// pass 1 (needs the target and the station positions only): the weight sum the image gradient is
-// divided by, and the number of stations that count.  Blocks [0, pixel_blocks) walk the
-// prediction grid, the others count stations.
-template <int V>
-__global__ __launch_bounds__(NT) void loss_weights_kernel(LossArgs a, double* __restrict__ ws, int pixel_blocks) {
-    __shared__ double smd[4];
-    if ((int)blockIdx.x < pixel_blocks) {
-        const double s = block_sum_256_d((double)pixel_pass<V, false>(a, pixel_blocks, 0.f, nullptr), smd);
-        if (threadIdx.x == 0) ws[WS_W + blockIdx.x] = s;
-    } else {
-        const int sb = (int)blockIdx.x - pixel_blocks, nsb = (int)gridDim.x - pixel_blocks;
-        const int half = a.ksize / 2;
-        double tc = 0.0;
-        for (int s = sb * NT + threadIdx.x; s < a.S; s += nsb * NT) {
-            const int px = a.pos[2 * s], py = a.pos[2 * s + 1];
-            const int wh = min(a.H, py + half + 1) - max(0, py - half), ww = min(a.W, px + half + 1) - max(0, px - half);
-            tc += (wh > 0 && ww > 0) ? 1.0 : 0.0;
-        }
-        tc = block_sum_256_d(tc, smd);
-        if (threadIdx.x == 0) ws[WS_SC + sb] = tc;
-    }
-}
-
-// pass 2: one read of pred and target; the image gradient (already divided by the weight sum)
-// goes to dpred, the block's sum of weighted pixel losses to the workspace; the station blocks
-// gather their window means.
+// pass 1: one read of pred and target; the unnormalised image gradient goes to dpred, the
+// block's partial sums to the workspace; the station blocks gather their window means.
 template <int V>
 __global__ __launch_bounds__(NT) void loss_main_kernel(LossArgs a, double* __restrict__ ws, float* __restrict__ dpred,
-                                                       int pixel_blocks, int pixel_blocks1) {
+                                                       int pixel_blocks) {
     __shared__ double smd[4];
     if ((int)blockIdx.x < pixel_blocks) {
-        const float inv_sw = (float)(1.0 / fold_partials(ws + WS_W, pixel_blocks1, smd));
-        const double s = block_sum_256_d((double)pixel_pass<V, true>(a, pixel_blocks, a.image_weight * inv_sw, dpred), smd);
-        if (threadIdx.x == 0) ws[WS_L + blockIdx.x] = s;
+        float accw = 0.f, accl = 0.f;
+        pixel_pass<V>(a, pixel_blocks, a.image_weight, dpred, accw, accl);
+        const double sw = block_sum_256_d((double)accw, smd);
+        const double sl = block_sum_256_d((double)accl, smd);
+        if (threadIdx.x == 0) { ws[WS_W + blockIdx.x] = sw; ws[WS_L + blockIdx.x] = sl; }
     } else {
         const int sb = (int)blockIdx.x - pixel_blocks, nsb = (int)gridDim.x - pixel_blocks;
         const int lane = threadIdx.x & 63;
-        double tl = 0.0;
+        double tl = 0.0, tc = 0.0;
         for (int s = sb * (NT / 64) + (threadIdx.x >> 6); s < a.S; s += nsb * (NT / 64)) {
             const int b = sample_of(a.offsets, a.B, s);
             int n, x0, y0, ww;
@@ -271,24 +246,26 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(LossArgs a, double* __res
             if (n > 0 && lane == 0) {
                 const float d = m - a.runoff[s];
                 tl += (double)(a.station_metric == 0 ? d * d : fabsf(d));
+                tc += 1.0;
             }
         }
         tl = block_sum_256_d(tl, smd);
-        if (threadIdx.x == 0) ws[WS_ST + sb] = tl;
+        tc = block_sum_256_d(tc, smd);
+        if (threadIdx.x == 0) { ws[WS_ST + sb] = tl; ws[WS_SC + sb] = tc; }
     }
 }
 
-// pass 3: block 0 folds the partials into the three losses; every block scatters the station
-// gradient of its stations (windows may overlap -> atomics) onto the image gradient.
+// pass 2: block 0 folds the partials into the three losses and 1 / sum w; every block scatters the
+// station gradient of its stations (windows may overlap -> atomics) onto the image gradient,
+// multiplied by sum w because the caller's 1 / sum w factor applies to all of dpred.
 __global__ __launch_bounds__(NT) void loss_finish_kernel(LossArgs a, const double* __restrict__ ws,
                                                          float* __restrict__ losses, float* __restrict__ dpred,
-                                                         int pixel_blocks1, int pixel_blocks2, int count_blocks,
-                                                         int station_blocks) {
+                                                         int pixel_blocks, int station_blocks) {
     __shared__ double smd[4];
-    const double cnt_d = fold_partials(ws + WS_SC, count_blocks, smd);
+    const double cnt_d = fold_partials(ws + WS_SC, station_blocks, smd);
+    const double sw = fold_partials(ws + WS_W, pixel_blocks, smd);
     if (blockIdx.x == 0) {
-        const double sw = fold_partials(ws + WS_W, pixel_blocks1, smd);
-        const double sl = fold_partials(ws + WS_L, pixel_blocks2, smd);
+        const double sl = fold_partials(ws + WS_L, pixel_blocks, smd);
         const double tl = fold_partials(ws + WS_ST, station_blocks, smd);
         if (threadIdx.x == 0) {
             const float img = (float)(sl / sw);
@@ -296,10 +273,12 @@ __global__ __launch_bounds__(NT) void loss_finish_kernel(LossArgs a, const doubl
             losses[1] = img;
             losses[2] = stn;
             losses[0] = a.image_weight * img + a.station_weight * stn;
+            losses[3] = (float)(1.0 / sw);
         }
     }
     const float cnt = (float)cnt_d;
     if (cnt <= 0.f) return;
+    const float swf = (float)sw;
     const int lane = threadIdx.x & 63;
     for (int s = (int)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); s < a.S; s += (int)gridDim.x * (NT / 64)) {
         const int b = sample_of(a.offsets, a.B, s);
@@ -308,7 +287,7 @@ __global__ __launch_bounds__(NT) void loss_finish_kernel(LossArgs a, const doubl
         if (n <= 0) continue;
         const float d = m - a.runoff[s];
         const float g = a.station_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        const float coef = a.station_weight * g / ((float)n * cnt);
+        const float coef = swf * (a.station_weight * g / ((float)n * cnt));
         for (int i = lane; i < n; i += 64)
             unsafeAtomicAdd(&dpred[((size_t)b * a.H + y0 + i / ww) * a.W + x0 + i % ww], coef);
     }
@@ -403,22 +382,13 @@ extern "C" int sf_image_station_loss(const float* pred, const float* target, con
     const bool vec = W % 4 == 0 && ((uintptr_t)pred | (uintptr_t)dpred | (uintptr_t)target) % 16 == 0 &&
                      (TW % 4 == 0 || TH != H || TW != W);
     SF_REQUIRE((long long)B * H < 0x7fffffffLL && total < (1LL << 40), "sf_image_station_loss: batch too large");
-    // a wave per row at a time: pass 1 only evaluates the target (several rows per wave), pass 2
-    // streams pred / dpred
+    // a wave per pair of rows at a time
     const long long rows = (long long)B * H;
-    int p1 = (int)((rows + 7) / 8); if (p1 > LP) p1 = LP; if (p1 < 1) p1 = 1;
-    int p2 = (int)((rows + 7) / 8); if (p2 > LP) p2 = LP; if (p2 < 1) p2 = 1;
-    int sb1 = (S + NT - 1) / NT; if (sb1 > LS) sb1 = LS; if (sb1 < 1) sb1 = 1;
-    int sb2 = (S + 3) / 4; if (sb2 > LS) sb2 = LS; if (sb2 < 1) sb2 = 1;
-    // the station slabs are written by sb2 (pass 2) and sb1 (pass 1) blocks and folded over exactly those
-    if (vec) {
-        hipLaunchKernelGGL(loss_weights_kernel<4>, dim3(p1 + sb1), dim3(NT), 0, s, a, ws, p1);
-        hipLaunchKernelGGL(loss_main_kernel<4>, dim3(p2 + sb2), dim3(NT), 0, s, a, ws, dpred, p2, p1);
-    } else {
-        hipLaunchKernelGGL(loss_weights_kernel<1>, dim3(p1 + sb1), dim3(NT), 0, s, a, ws, p1);
-        hipLaunchKernelGGL(loss_main_kernel<1>, dim3(p2 + sb2), dim3(NT), 0, s, a, ws, dpred, p2, p1);
-    }
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(sb2), dim3(NT), 0, s, a, ws, losses, dpred, p1, p2, sb1, sb2);
+    int pb = (int)((rows + 7) / 8); if (pb > LP) pb = LP; if (pb < 1) pb = 1;
+    int sb = (S + 3) / 4; if (sb > LS) sb = LS; if (sb < 1) sb = 1;
+    if (vec) hipLaunchKernelGGL(loss_main_kernel<4>, dim3(pb + sb), dim3(NT), 0, s, a, ws, dpred, pb);
+    else hipLaunchKernelGGL(loss_main_kernel<1>, dim3(pb + sb), dim3(NT), 0, s, a, ws, dpred, pb);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(sb), dim3(NT), 0, s, a, ws, losses, dpred, pb, sb);
     SF_LAUNCH_CHECK("sf_image_station_loss");
     return SF_OK;
 }

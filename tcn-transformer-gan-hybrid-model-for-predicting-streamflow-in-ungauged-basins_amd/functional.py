@@ -541,13 +541,14 @@ class ImageStationLossFn(torch.autograd.Function):
         losses, dpred = ops.image_station_loss(pred.contiguous().float(), target.contiguous().float(), pos, runoff,
                                                offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
                                                station_metric, iw, sw)
-        ctx.save_for_backward(dpred)
-        return losses
+        ctx.save_for_backward(dpred, losses)
+        return losses[:3]
 
     @staticmethod
     def backward(ctx, g):
-        (dpred,) = ctx.saved_tensors
-        return dpred * g[0], None, None, None, None, None, None
+        # the kernel leaves the division by the weight sum (losses[3] = its inverse) to this product
+        dpred, losses = ctx.saved_tensors
+        return dpred * (g[0] * losses[3]), None, None, None, None, None, None
 
 
 class BceLogitsFn(torch.autograd.Function):

@@ -697,12 +697,13 @@ def lonlat_to_pixel(lon: torch.Tensor, lat: torch.Tensor, region, W: int, H: int
 
 def image_station_loss(pred, target, pos, runoff, offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
                        station_metric, image_weight, station_weight):
-    """Returns (losses[3] = total, image, station; dpred)."""
+    """Returns (losses f32 [4] = total, image, station, 1 / weight sum; dpred): the gradient of
+    the total loss with respect to pred is dpred * losses[3]."""
     _dev(pred, target, pos, runoff, offsets,
          dtypes=[torch.float32, torch.float32, torch.int32, torch.float32, torch.int32])
     B, _, H, W = pred.shape
     TH, TW = target.shape[-2], target.shape[-1]
-    losses = torch.empty(3, device=pred.device, dtype=torch.float32)
+    losses = torch.empty(4, device=pred.device, dtype=torch.float32)
     dpred = torch.empty_like(pred)
     ws = torch.empty(LOSS_WS_DOUBLES, device=pred.device, dtype=torch.float64)
     _check(lib().sf_image_station_loss(_p(pred), _p(target), _p(pos), _p(runoff), _p(offsets), S, B, H, W, TH, TW,

@@ -32,4 +32,4 @@ for B in (32, 256):
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 50
     nbytes = pred.numel() * 8 + tgt.numel() * 4 + B * S * 12
-    print(f"B={B}: {t * 1e3:.1f} us per call (3 launches), {nbytes / 1e6:.1f} MB algorithmic -> {nbytes / t / 1e6:.0f} GB/s", flush=True)
+    print(f"B={B}: {t * 1e3:.1f} us per call (2 launches), {nbytes / 1e6:.1f} MB algorithmic -> {nbytes / t / 1e6:.0f} GB/s", flush=True)
