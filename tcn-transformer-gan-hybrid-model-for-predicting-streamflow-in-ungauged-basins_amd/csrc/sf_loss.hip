@@ -325,11 +325,34 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-__global__ void colsum_f32_kernel(const float* __restrict__ x, long long M, long long C, float* __restrict__ out) {
-    for (long long c = blockIdx.x * (long long)NT + threadIdx.x; c < C; c += (long long)gridDim.x * NT) {
-        float a = 0.f;
-        for (long long m = 0; m < M; ++m) a += x[m * C + c];
-        out[c] = a;
+// out[c] = sum_m x[m][c].  A block owns 32 columns; its 8 row groups each take every 8th row,
+// four loads in flight (rows past the end read row M-1 with weight 0), and are folded through
+// LDS in a fixed order.  Both shapes of the Linear bias gradients are latency bound: [32 x
+// 262144] (many blocks, four rows each) and [160 x 128] (four blocks, twenty rows per thread).
+__global__ __launch_bounds__(NT) void colsum_f32_kernel(const float* __restrict__ x, long long M, long long C,
+                                                        float* __restrict__ out) {
+    __shared__ float sm[8][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long long c = (long long)blockIdx.x * 32 + cl;
+    const long long cc = c < C ? c : C - 1;
+    float a = 0.f;
+    for (long long m = rg; m < M; m += 32) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long mm = m + 8 * u;
+            v[u] = x[(mm < M ? mm : M - 1) * C + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += (m + 8 * u < M) ? v[u] : 0.f;
+    }
+    sm[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sm[g][cl];
+        out[c] = t;
     }
 }
 
@@ -418,7 +441,8 @@ extern "C" int sf_adam(float* p, const float* g, float* m, float* v, long long n
 
 extern "C" int sf_colsum_f32(const float* x, long long M, long long C, float* out, void* stream) {
     SF_REQUIRE(x && out && M > 0 && C > 0, "sf_colsum_f32: bad arguments");
-    long long grid = (C + NT - 1) / NT; if (grid > 4096) grid = 4096;
+    const long long grid = (C + 31) / 32;
+    SF_REQUIRE(grid <= 0x7fffffffLL, "sf_colsum_f32: too many columns");
     hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)stream, x, M, C, out);
     SF_LAUNCH_CHECK("sf_colsum_f32");
     return SF_OK;

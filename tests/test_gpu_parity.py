@@ -710,3 +710,13 @@ def test_trainer_validate(sf):
     want = O.calculate_metrics(torch.cat(ps).numpy(), torch.cat(ts).numpy())
     for k in ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE"):
         assert abs(res[k] - want[k]) <= 1e-4 * max(1.0, abs(want[k])), k
+
+
+def test_colsum_f32_shapes(sf):
+    """Bias-gradient column sums of the two Linear layers (short and very wide, tall and narrow),
+    odd sizes and a single element, against a float64 sum."""
+    torch.manual_seed(1)
+    for (M, C) in [(160, 128), (32, 262144), (7, 33), (1, 1), (100, 31)]:
+        x = torch.randn(M, C, device=DEV)
+        got = sf.ops.colsum_f32(x)
+        close(got, x.double().sum(0).cpu().numpy(), 1e-6)
