@@ -483,7 +483,8 @@ def test_conv3x3_kernels_against_f32_conv(sf):
     ops = sf.ops
     torch.manual_seed(3)
     cases = [(2, 37, 53, 16, 24), (1, 100, 100, 64, 64), (3, 20, 61, 32, 136), (2, 9, 200, 48, 72),
-             (1, 1, 70, 96, 8), (2, 33, 33, 256, 64)]
+             (1, 1, 70, 96, 8), (2, 33, 33, 256, 64),
+             (1, 9, 11, 16, 1032)]          # more than 1024 output channels: the register-staged kernel
     for (N, H, W, C, K) in cases:
         x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
         w = (torch.randn(K, C, 3, 3, device=DEV) * (1.0 / (3.0 * C ** 0.5))).to(torch.bfloat16).float()
