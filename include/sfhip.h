@@ -150,10 +150,14 @@ int sf_bn_relu_avgpool_fwd(const void* x, int dtype, const float* scale, const f
 /* y = leaky_relu(x*scale+shift, 0.2), NHWC -> NHWC */
 int sf_bn_lrelu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
                     long long M, int C, void* stream);
+/* y = relu(x*scale+shift), NHWC -> NHWC (the Conv-BN-ReLU blocks of LightweightCNNReducer,
+ * src/model/baseline_models.py:37-50) */
+int sf_bn_relu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
+                   long long M, int C, void* stream);
 /*
  * BatchNorm backward fused with the backward of what follows it.  mode 0: ReLU+maxpool2x2
  * (dy = gradient wrt the pooled map, NHWC dtype); mode 1: ReLU+adaptive avgpool (dy = NHWC
- * dtype [N,OH,OW,C]); mode 2: LeakyReLU(0.2) (dy NHWC dtype).
+ * dtype [N,OH,OW,C]); mode 2: LeakyReLU(0.2) (dy NHWC dtype); mode 3: ReLU, no pooling (dy NHWC dtype).
  * Pass 1 (sf_bn_bwd_reduce) accumulates sum(dz) and sum(dz*xhat) per channel into ws
  * (2*C doubles, zeroed here); pass 2 (sf_bn_bwd_apply) writes
  * dx = scale*(dz - mean(dz) - xhat*mean(dz*xhat)) (training) or scale*dz (eval) and
@@ -364,6 +368,15 @@ int sf_gather_frames(const float* src, long long src_stride, long long n_src,
 size_t sf_date_image_metrics_workspace_bytes(int B, int H, int W);
 int sf_date_image_metrics(const float* pred, const float* target, int B, int H, int W, double* out,
                           void* ws, size_t ws_bytes, void* stream);
+
+/* ---- baseline models ------------------------------------------------------------------------- */
+/* y = dropout(relu(x), p) over n f32 elements (the MLP of PureBPModel,
+ * src/model/baseline_models.py:181-190): kept elements scaled by 1/(1-p), the mask drawn from
+ * `seed` per element index; p = 0 is a plain ReLU.  Backward: dx = dy/(1-p) where y > 0. */
+int sf_relu_dropout_fwd(const float* x, float* y, long long n, float p, unsigned long long seed,
+                        void* stream);
+int sf_relu_dropout_bwd(const float* y, const float* dy, float* dx, long long n, float p,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -191,11 +191,11 @@ __global__ __launch_bounds__(BT) void bn_relu_maxpool_fwd_kernel(const T* __rest
     }
 }
 
-// y = leaky_relu(x*scale+shift, 0.2); item = one row
+// y = leaky_relu(x*scale+shift, slope) (slope 0: ReLU); item = one row
 template <typename T>
 __global__ __launch_bounds__(BT) void bn_lrelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, T* __restrict__ y,
-                                                          unsigned M, unsigned per, int C) {
+                                                          unsigned M, unsigned per, int C, float slope) {
     constexpr int EPC = Chunk<T>::EPC, U = 4;
     const RowMap m(C, EPC);
     if (!m.active) return;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(BT) void bn_lrelu_fwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const float v = f[e] * sc[e] + sf[e];
-                f[e] = v > 0.f ? v : 0.2f * v;
+                f[e] = v > 0.f ? v : slope * v;
             }
             *reinterpret_cast<uint4*>(y + (size_t)rr * C + m.cg * EPC) = Chunk<T>::encode(f);
         }
@@ -233,6 +233,7 @@ struct BnBwd {
     const float* scale; const float* shift; const float* mean; const float* invstd; const float* gamma;
     int N, H, W, C, Creal, OH, OW, training;
     unsigned items, per;
+    float slope;   // negative-side slope of the activation in mode 2 (LeakyReLU 0.2) / 3 (ReLU: 0)
 };
 
 // adaptive average pool bins (ATen): bin i covers [floor(i*in/out), ceil((i+1)*in/out))
@@ -301,7 +302,7 @@ template <typename T, int MODE> struct BwdBatch {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float y = xf[u][0][e] * ch.sc[e] + ch.sf[e];
-                    dz[u][0][e] = y > 0.f ? g[e] : 0.2f * g[e];
+                    dz[u][0][e] = y > 0.f ? g[e] : a.slope * g[e];
                 }
             }
         } else if constexpr (MODE == 1) {
@@ -622,22 +623,32 @@ extern "C" int sf_bn_relu_maxpool_fwd(const void* x, int dtype, const float* sca
     return SF_OK;
 }
 
-extern "C" int sf_bn_lrelu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
-                               long long M, int C, void* stream) {
-    SF_REQUIRE(x && y && scale && shift && M > 0 && M < 0x7fffffffLL, "sf_bn_lrelu_fwd: bad arguments");
-    if (int rc = check_chunked("sf_bn_lrelu_fwd", dtype, C)) return rc;
+static int bn_act_fwd(const char* who, const void* x, int dtype, const float* scale, const float* shift, void* y,
+                      long long M, int C, float slope, void* stream) {
+    SF_REQUIRE(x && y && scale && shift && M > 0 && M < 0x7fffffffLL, "%s: bad arguments", who);
+    if (int rc = check_chunked(who, dtype, C)) return rc;
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const Split sp = split_rows(M, (BT / (C / epc)) * 4, 4096);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_lrelu_fwd_kernel<T>, dim3(sp.grid), dim3(BT), 0, (hipStream_t)stream,
-                                         (const T*)x, scale, shift, (T*)y, (unsigned)M, sp.per, C));
-    SF_LAUNCH_CHECK("sf_bn_lrelu_fwd");
+                                         (const T*)x, scale, shift, (T*)y, (unsigned)M, sp.per, C, slope));
+    SF_LAUNCH_CHECK(who);
     return SF_OK;
+}
+
+extern "C" int sf_bn_lrelu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y,
+                               long long M, int C, void* stream) {
+    return bn_act_fwd("sf_bn_lrelu_fwd", x, dtype, scale, shift, y, M, C, 0.2f, stream);
+}
+
+extern "C" int sf_bn_relu_fwd(const void* x, int dtype, const float* scale, const float* shift, void* y, long long M,
+                              int C, void* stream) {
+    return bn_act_fwd("sf_bn_relu_fwd", x, dtype, scale, shift, y, M, C, 0.f, stream);
 }
 
 static int fill_bnbwd(BnBwd& a, int mode, const void* x, const void* dy, const float* scale, const float* shift,
                       const float* mean, const float* invstd, const float* gamma, int N, int H, int W, int C,
                       int Creal, int OH, int OW, int training, int dtype, int dy_dtype, int cap) {
-    SF_REQUIRE(mode >= 0 && mode <= 2, "bn_bwd: bad mode %d", mode);
+    SF_REQUIRE(mode >= 0 && mode <= 3, "bn_bwd: bad mode %d", mode);
     SF_REQUIRE(x && dy && scale && shift && mean && invstd, "bn_bwd: null argument");
     SF_REQUIRE(dy_dtype == dtype, "bn_bwd: dy dtype must equal x dtype");
     SF_REQUIRE(N > 0 && H > 0 && W > 0 && Creal <= C, "bn_bwd: bad shape");
@@ -650,6 +661,7 @@ static int fill_bnbwd(BnBwd& a, int mode, const void* x, const void* dy, const f
     if (int rc = check_chunked("bn_bwd", dtype, C)) return rc;
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
     a.N = N; a.H = H; a.W = W; a.C = C; a.Creal = Creal; a.OH = OH; a.OW = OW; a.training = training;
+    a.slope = mode == 3 ? 0.f : 0.2f;
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const long long items = mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
     const Split sp = split_rows(items, (BT / (C / epc)) * (mode == 0 ? 2 : 4), cap, cap <= 512 ? 32 : 1);
@@ -669,7 +681,7 @@ extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* 
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { sf_set_error("sf_bn_bwd_reduce: memset failed"); return SF_ELAUNCH; }
 #define RED(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), dim3(grid), dim3(BT), 0, s, a, ws))
-    if (mode == 0) { RED(0); } else if (mode == 1) { RED(1); } else { RED(2); }
+    if (mode == 0) { RED(0); } else if (mode == 1) { RED(1); } else { RED(2); }   // modes 2 and 3 differ in a.slope only
 #undef RED
     SF_LAUNCH_CHECK("sf_bn_bwd_reduce");
     return SF_OK;

@@ -102,6 +102,15 @@ __device__ __forceinline__ double block_sum_256_d(double v, double* sm) {
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// uniform [0,1) from a 64-bit seed and an element index (splitmix64 finaliser): the dropout masks
+__device__ __forceinline__ float rand_u(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 // bilinear source index / weights of one axis
 struct AxisW { int i0, i1; float l0, l1; };
 __device__ __forceinline__ AxisW axis_w(int dst, int in, int out) {

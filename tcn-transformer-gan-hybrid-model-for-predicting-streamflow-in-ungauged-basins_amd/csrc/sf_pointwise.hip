@@ -610,3 +610,41 @@ extern "C" int sf_bilinear_bwd(const void* ddst, int dtype, float* dsrc, float* 
     SF_LAUNCH_CHECK("sf_bilinear_bwd");
     return SF_OK;
 }
+
+// ------------------------------------------------------------------------------ ReLU + dropout
+// y = dropout(relu(x), p): the Linear -> ReLU -> Dropout steps of PureBPModel's MLP
+// (src/model/baseline_models.py:181-190).  Kept elements are scaled by 1 / (1 - p); the mask of
+// element i is rand_u(seed, i) >= p.  The backward needs no seed: y > 0 exactly where the
+// element passed both the ReLU and the mask.
+__global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               long long n, float p, unsigned long long seed) {
+    const float keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        const float m = (p > 0.f && rand_u(seed, (unsigned long long)i) < p) ? 0.f : keep;
+        y[i] = v > 0.f ? v * m : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, long long n, float p) {
+    const float keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dx[i] = y[i] > 0.f ? dy[i] * keep : 0.f;
+}
+
+extern "C" int sf_relu_dropout_fwd(const float* x, float* y, long long n, float p, unsigned long long seed,
+                                   void* stream) {
+    SF_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "sf_relu_dropout_fwd: bad arguments");
+    long long grid = (n + 255) / 256; if (grid > 4096) grid = 4096;
+    relu_dropout_fwd_kernel<<<dim3((unsigned)grid), 256, 0, (hipStream_t)stream>>>(x, y, n, p, seed);
+    SF_LAUNCH_CHECK("sf_relu_dropout_fwd");
+    return SF_OK;
+}
+
+extern "C" int sf_relu_dropout_bwd(const float* y, const float* dy, float* dx, long long n, float p, void* stream) {
+    SF_REQUIRE(y && dy && dx && n > 0 && p >= 0.f && p < 1.f, "sf_relu_dropout_bwd: bad arguments");
+    long long grid = (n + 255) / 256; if (grid > 4096) grid = 4096;
+    relu_dropout_bwd_kernel<<<dim3((unsigned)grid), 256, 0, (hipStream_t)stream>>>(y, dy, dx, n, p);
+    SF_LAUNCH_CHECK("sf_relu_dropout_bwd");
+    return SF_OK;
+}

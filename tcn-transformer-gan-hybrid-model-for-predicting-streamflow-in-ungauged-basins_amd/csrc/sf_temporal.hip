@@ -15,13 +15,6 @@ struct MPtrs12 { float* p[12]; };
 struct Ptrs16 { const float* p[16]; };
 struct MPtrs16 { float* p[16]; };
 
-__device__ __forceinline__ float rand_u(unsigned long long seed, unsigned long long idx) {
-    unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
 // multiplicative dropout mask value (0 or 1/(1-p)) for element i of site s of sample b
 __device__ __forceinline__ float drop_mask(float p, unsigned long long seed, int b, int site, int i) {
     if (p <= 0.f) return 1.f;

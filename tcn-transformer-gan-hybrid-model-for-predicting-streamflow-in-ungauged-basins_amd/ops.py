@@ -71,7 +71,8 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
            "sf_bce_logits", "sf_adam", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
-           "sf_gather_frames", "sf_date_image_metrics", "sf_date_image_metrics_workspace_bytes"]
+           "sf_gather_frames", "sf_date_image_metrics", "sf_date_image_metrics_workspace_bytes", "sf_bn_relu_fwd",
+           "sf_relu_dropout_fwd", "sf_relu_dropout_bwd"]
 
 
 def _check(rc: int, who: str):
@@ -425,6 +426,29 @@ def bn_lrelu_fwd(x, st):
     _check(lib().sf_bn_lrelu_fwd(_p(x), code_of(x.dtype), _p(st[0]), _p(st[1]), _p(y), _c_ll(x.numel() // C), C,
                                  _stream()), "sf_bn_lrelu_fwd")
     return y
+
+
+def bn_relu_fwd(x, st):
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    _check(lib().sf_bn_relu_fwd(_p(x), code_of(x.dtype), _p(st[0]), _p(st[1]), _p(y), _c_ll(x.numel() // C), C,
+                                _stream()), "sf_bn_relu_fwd")
+    return y
+
+
+def relu_dropout_fwd(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    _dev(x, dtypes=[torch.float32])
+    y = torch.empty_like(x)
+    _check(lib().sf_relu_dropout_fwd(_p(x), _p(y), _c_ll(x.numel()), _c_f(p), ctypes.c_ulonglong(seed), _stream()),
+           "sf_relu_dropout_fwd")
+    return y
+
+
+def relu_dropout_bwd(y: torch.Tensor, dy: torch.Tensor, p: float) -> torch.Tensor:
+    _dev(y, dy, dtypes=[torch.float32, torch.float32])
+    dx = torch.empty_like(y)
+    _check(lib().sf_relu_dropout_bwd(_p(y), _p(dy), _p(dx), _c_ll(y.numel()), _c_f(p), _stream()), "sf_relu_dropout_bwd")
+    return dx
 
 
 def bn_backward(mode, x, dy, st, gamma, Creal, training, OH=0, OW=0):

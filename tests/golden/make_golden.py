@@ -483,11 +483,46 @@ def gen_ckpt():
     save("checkpoint_keys", **out)
 
 
+def gen_baselines():
+    """PureLSTMModel / PureBPModel (src/model/baseline_models.py): eval forward, train forward,
+    gradients of sum(y * u) for every parameter (checksums; a few in full), BatchNorm buffers
+    after the training forward.  Dropout is zeroed."""
+    from src.model.baseline_models import build_baseline_model
+    out = {}
+    cfg = {"model": {"input_channels": 3, "hidden_dim": 32, "num_layers": 2},
+           "data": {"image_size": [64, 64], "upscale_factor": 2, "window_size": 5}}
+    x = G.gold_tensor("base/x", (2, 5, 3, 64, 64))
+    u = G.gold_tensor("base/u", (2, 1, 128, 128))
+    for name in ("LSTM", "BP"):
+        m = build_baseline_model(name, cfg)
+        load_gold(m, "base_" + name)
+        zero_dropout(m)
+        m.eval()
+        with torch.no_grad():
+            out[f"{name}_eval"] = m(x)
+        m.train()
+        y = m(x)
+        (y * u).sum().backward()
+        out[f"{name}_train"] = y
+        grads = {k: p.grad for k, p in m.named_parameters()}
+        cs = G.checksum(grads)
+        out[f"{name}_gkeys"] = np.array(list(cs.keys()))
+        out[f"{name}_gsum"] = np.stack([cs[k] for k in cs])
+        for k in ("reducer.encoder.0.weight", "reducer.encoder.6.weight", "reducer.encoder.4.weight", "decoder.0.bias",
+                  "decoder.2.weight", "head_proj.bias"):
+            out[f"{name}_g_{k}"] = grads[k]
+        sd = m.state_dict()
+        out[f"{name}_keys"] = np.array(list(sd.keys()))
+        out[f"{name}_rm7"] = sd["reducer.encoder.7.running_mean"]
+        out[f"{name}_rv1"] = sd["reducer.encoder.1.running_var"]
+    save("baselines", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pixel", "encoder", "temporal", "decoder", "disc", "losses", "generator",
-                             "train", "evaluate", "dataset", "ckpt"]
+                             "train", "evaluate", "dataset", "ckpt", "baselines"]
     fns = {"pixel": gen_pixel, "encoder": gen_encoder, "temporal": gen_temporal, "decoder": gen_decoder,
            "disc": gen_disc, "losses": gen_losses, "generator": gen_generator, "train": gen_train,
-           "evaluate": gen_evaluate, "dataset": gen_dataset, "ckpt": gen_ckpt}
+           "evaluate": gen_evaluate, "dataset": gen_dataset, "ckpt": gen_ckpt, "baselines": gen_baselines}
     for w in which:
         fns[w]()

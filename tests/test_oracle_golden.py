@@ -392,3 +392,44 @@ def test_dataset_restatement(oracle, tag):
         close(np.nan_to_num(s["output_image"]), np.nan_to_num(ref_t), 1e-5)
         assert np.array_equal(s["station_positions"], g[f"{tag}_pos{i}"])
         np.testing.assert_allclose(s["stations"], g[f"{tag}_stations{i}"], rtol=1e-6)
+
+
+def baseline_shapes(name, cin=3, hidden=32, layers=2, window=5):
+    """state_dict shapes of PureLSTMModel / PureBPModel, restated from src/model/baseline_models.py."""
+    s = {}
+    ch = [cin, 32, 32, 16]
+    for li, i in enumerate((0, 3, 6)):
+        s[f"reducer.encoder.{i}.weight"] = (ch[li + 1], ch[li], 3, 3)
+        for nm in ("weight", "bias", "running_mean", "running_var"):
+            s[f"reducer.encoder.{i + 1}.{nm}"] = (ch[li + 1],)
+        s[f"reducer.encoder.{i + 1}.num_batches_tracked"] = ()
+    if name == "LSTM":
+        s["input_proj.weight"], s["input_proj.bias"] = (hidden, 1024), (hidden,)
+        for l in range(layers):
+            s[f"lstm.weight_ih_l{l}"], s[f"lstm.weight_hh_l{l}"] = (4 * hidden, hidden), (4 * hidden, hidden)
+            s[f"lstm.bias_ih_l{l}"], s[f"lstm.bias_hh_l{l}"] = (4 * hidden,), (4 * hidden,)
+        head_in = hidden
+    else:
+        dims = [window * 1024, 4 * hidden, 4 * hidden, 2 * hidden]
+        for j, i in enumerate((0, 3, 6)):
+            s[f"mlp.{i}.weight"], s[f"mlp.{i}.bias"] = (dims[j + 1], dims[j]), (dims[j + 1],)
+        head_in = 2 * hidden
+    s["head_proj.weight"], s["head_proj.bias"] = (4096, head_in), (4096,)
+    s["decoder.0.weight"], s["decoder.0.bias"] = (64, 64, 3, 3), (64,)
+    s["decoder.2.weight"], s["decoder.2.bias"] = (1, 64, 1, 1), (1,)
+    return s
+
+
+@pytest.mark.parametrize("name", ["LSTM", "BP"])
+def test_baseline_models_restatement(name):
+    g = golden("baselines")
+    shapes = baseline_shapes(name)
+    assert list(shapes.keys()) == [str(k) for k in g[f"{name}_keys"]]          # the reference's keys, in its order
+    sd = G.gold_state(shapes, "base_" + name)
+    x = G.gold_tensor("base/x", (2, 5, 3, 64, 64))
+    y, _ = O.baseline_forward(x, sd, name, 128, 128, training=False)
+    close(y, g[f"{name}_eval"], 1e-5)
+    y, new = O.baseline_forward(x, sd, name, 128, 128, training=True)
+    close(y, g[f"{name}_train"], 1e-5)
+    close(new["reducer.encoder.7.running_mean"], g[f"{name}_rm7"], 1e-5)
+    close(new["reducer.encoder.1.running_var"], g[f"{name}_rv1"], 1e-5)

@@ -1,0 +1,33 @@
+"""Forward + backward throughput of the baseline models at their reference shape
+(10 channels, 256 x 256, T = 5, hidden 64, batch 32), f32 and bf16."""
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sf = importlib.import_module("tcn-transformer-gan-hybrid-model-for-predicting-streamflow-in-ungauged-basins_amd")
+cfg = {"model": {"input_channels": 10, "hidden_dim": 64, "num_layers": 2},
+       "data": {"image_size": [256, 256], "upscale_factor": 1, "window_size": 5}}
+B = 32
+x = torch.randn(B, 5, 10, 256, 256, device="cuda")
+for name in ("LSTM", "BP"):
+    m = sf.build_baseline_model(name, cfg).cuda().train()
+    for amp in (False, True):
+        def step():
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                y = m(x)
+            y.float().mean().backward()
+            for p in m.parameters():
+                p.grad = None
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        print(f"{name:5s} {'bf16' if amp else 'f32 '}  {dt * 1e3:7.2f} ms / step   {B / dt:8.0f} samples/s", flush=True)
