@@ -377,6 +377,26 @@ int sf_relu_dropout_fwd(const float* x, float* y, long long n, float p, unsigned
                         void* stream);
 int sf_relu_dropout_bwd(const float* y, const float* dy, float* dx, long long n, float p,
                         void* stream);
+/* nn.GRU(H, H, L, batch_first=True) of AttentionGRUModel (src/model/baseline_models.py:289-296,316):
+ * x f32 [B,T,H] -> y f32 [B,T,H], the output sequence of the last layer (gate order r, z, n;
+ * inter-layer dropout p_drop drawn from seed).  w: 4*L device pointers weight_ih_l, weight_hh_l
+ * [3H,H], bias_ih_l, bias_hh_l [3H].  save (nullable in inference): B * sf_gru_save_floats floats.
+ * Backward: dy f32 [B,T,H] -> dx; dw (same order as w) accumulated with atomics, zeroed by the
+ * caller.  T <= 8, H % 4 == 0, L <= 4. */
+size_t sf_gru_save_floats(int T, int H, int L);
+int sf_gru_fwd(const float* x, float* y, const float* const* w, float* save, int B, int T, int H,
+               int L, float p_drop, unsigned long long seed, void* stream);
+int sf_gru_bwd(const float* x, const float* dy, float* dx, const float* const* w, float* const* dw,
+               const float* save, int B, int T, int H, int L, float p_drop,
+               unsigned long long seed, void* stream);
+/* TemporalAttention.forward (src/model/baseline_models.py:221-247): Q, K, V = Linear(g),
+ * softmax(Q K^T / sqrt(H)) V averaged over time: g f32 [B,T,H] -> out f32 [B,H].  w = {Wq, bq, Wk,
+ * bk, Wv, bv}; save: B * sf_attn_save_floats floats; dw accumulated with atomics. */
+size_t sf_attn_save_floats(int T, int H);
+int sf_attn_fwd(const float* g, float* out, const float* const* w, float* save, int B, int T, int H,
+                void* stream);
+int sf_attn_bwd(const float* g, const float* dout, float* dg, const float* const* w,
+                float* const* dw, const float* save, int B, int T, int H, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ There is no CPU or eager-PyTorch fallback: without the built library or without 
 modules raise.
 """
 from . import ops
-from .baselines import LightweightCNNReducer, PureBPModel, PureLSTMModel, build_baseline_model
+from .baselines import AttentionGRUModel, LightweightCNNReducer, PureBPModel, PureLSTMModel, build_baseline_model
 from .dataset import ResidentStreamflowDataset, window_shards
 from .evaluation import Evaluator, calculate_metrics, calculate_psnr, calculate_ssim, merge_partials
 from .functional import compute_dtype, set_compute_dtype
@@ -14,7 +14,7 @@ from .modules import (CNNEncoder, CombinedLoss, GANLoss, ImageLoss, LSTMModule, 
                       PositionalEncoding, SimpleUpsamplingDecoder, StationLoss, StreamflowPredictionModel,
                       TransformerModule)
 
-__all__ = ["ops", "LightweightCNNReducer", "PureBPModel", "PureLSTMModel", "build_baseline_model", "ResidentStreamflowDataset", "window_shards", "compute_dtype", "set_compute_dtype", "CNNEncoder", "CombinedLoss", "GANLoss", "ImageLoss",
+__all__ = ["ops", "AttentionGRUModel", "LightweightCNNReducer", "PureBPModel", "PureLSTMModel", "build_baseline_model", "ResidentStreamflowDataset", "window_shards", "compute_dtype", "set_compute_dtype", "CNNEncoder", "CombinedLoss", "GANLoss", "ImageLoss",
            "LSTMModule", "PatchDiscriminator", "PositionalEncoding", "SimpleUpsamplingDecoder", "StationLoss",
            "StreamflowPredictionModel", "TransformerModule", "Evaluator", "calculate_metrics", "calculate_psnr",
            "calculate_ssim", "merge_partials"]

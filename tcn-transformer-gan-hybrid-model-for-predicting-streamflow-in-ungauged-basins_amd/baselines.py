@@ -1,7 +1,7 @@
 """Baseline comparison models of the reference (src/model/baseline_models.py) on the HIP kernels:
-LightweightCNNReducer, PureLSTMModel ('LSTM') and PureBPModel ('BP'), with the reference's
-constructor arguments, forward signature and state_dict keys.  AttentionGRUModel needs a GRU
-kernel this library does not have and is not built (build_baseline_model says so).
+LightweightCNNReducer, PureLSTMModel ('LSTM'), PureBPModel ('BP') and AttentionGRUModel
+('Attention-GRU'), with the reference's constructor arguments, forward signature and state_dict
+keys.
 
 The reducer's stride-2 3x3 convolutions run on the generic implicit-GEMM kernel (forward, weight
 gradient, and the data gradient as four parity classes in one launch); BatchNorm, the Linear
@@ -130,6 +130,45 @@ class ReluDropoutFn(torch.autograd.Function):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         return ops.relu_dropout_bwd(y, dy.contiguous().float(), ctx.p), None, None
+
+
+class GruFn(torch.autograd.Function):
+    """nn.GRU(H, H, L, batch_first=True)(x)[0]: the output sequence of the last layer."""
+
+    @staticmethod
+    def forward(ctx, x, L, p_drop, seed, *ws):
+        wsd = [w.detach().contiguous() for w in ws]
+        x = x.contiguous().float()
+        y, save = ops.gru_fwd(x, wsd, L, p_drop, seed, any(ctx.needs_input_grad))
+        ctx.x, ctx.save, ctx.ws, ctx.cfg = x, save, wsd, (L, p_drop, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L, p_drop, seed = ctx.cfg
+        dws = [torch.zeros_like(w) for w in ctx.ws]
+        dx = ops.gru_bwd(ctx.x, dy.contiguous().float(), ctx.ws, dws, ctx.save, L, p_drop, seed)
+        ctx.x = ctx.save = None
+        return (dx, None, None, None, *dws)
+
+
+class TemporalAttentionFn(torch.autograd.Function):
+    """TemporalAttention.forward (src/model/baseline_models.py:231-247)."""
+
+    @staticmethod
+    def forward(ctx, g, *ws):
+        wsd = [w.detach().contiguous() for w in ws]
+        g = g.contiguous().float()
+        out, save = ops.attn_fwd(g, wsd, any(ctx.needs_input_grad))
+        ctx.g, ctx.save, ctx.ws = g, save, wsd
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dws = [torch.zeros_like(w) for w in ctx.ws]
+        dg = ops.attn_bwd(ctx.g, dout.contiguous().float(), ctx.ws, dws, ctx.save)
+        ctx.g = ctx.save = None
+        return (dg, *dws)
 
 
 class HeadFn(torch.autograd.Function):
@@ -299,13 +338,53 @@ class PureBPModel(_BaselineBase):
         return self._head(x)
 
 
-BASELINE_MODELS = {"LSTM": PureLSTMModel, "BP": PureBPModel}
+class TemporalAttention(nn.Module):
+    """Mirror of src/model/baseline_models.py:221-247."""
+
+    def __init__(self, hidden_dim: int):
+        super().__init__()
+        self.query = nn.Linear(hidden_dim, hidden_dim)
+        self.key = nn.Linear(hidden_dim, hidden_dim)
+        self.value = nn.Linear(hidden_dim, hidden_dim)
+        self.scale = hidden_dim ** 0.5
+
+    def forward(self, gru_outputs: torch.Tensor) -> torch.Tensor:
+        _need_cuda(gru_outputs, "TemporalAttention")
+        return TemporalAttentionFn.apply(gru_outputs, self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+                                         self.value.weight, self.value.bias)
+
+
+class AttentionGRUModel(_BaselineBase):
+    """Mirror of src/model/baseline_models.py:250-326: reducer -> Linear -> GRU -> attention -> head."""
+
+    def __init__(self, config: Dict):
+        hidden = config.get("model", {}).get("hidden_dim", 64)
+        super().__init__(config, hidden)
+        flat = self.cnn_out_ch * self.reduce_size * self.reduce_size
+        self.input_proj = nn.Linear(flat, self.hidden_dim)
+        self.gru = nn.GRU(input_size=self.hidden_dim, hidden_size=self.hidden_dim, num_layers=self.num_layers,
+                          dropout=0.2 if self.num_layers > 1 else 0, batch_first=True)
+        self.attention = TemporalAttention(self.hidden_dim)
+        self._make_head()
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        B, T = images.shape[0], images.shape[1]
+        x = self._reduce(images).reshape(B * T, -1)
+        x = SF.LinearFn.apply(x, self.input_proj.weight, self.input_proj.bias, SF.compute_dtype()).view(B, T, -1)
+        p = float(self.gru.dropout) if self.training else 0.0
+        ws = []
+        for l in range(self.num_layers):
+            ws += [getattr(self.gru, f"weight_ih_l{l}"), getattr(self.gru, f"weight_hh_l{l}"),
+                   getattr(self.gru, f"bias_ih_l{l}"), getattr(self.gru, f"bias_hh_l{l}")]
+        g = GruFn.apply(x, self.num_layers, p, SF.new_seed() if p > 0 else 0, *ws)
+        return self._head(self.attention(g))
+
+
+BASELINE_MODELS = {"LSTM": PureLSTMModel, "BP": PureBPModel, "Attention-GRU": AttentionGRUModel}
 
 
 def build_baseline_model(name: str, config: Dict) -> nn.Module:
     """src/model/baseline_models.py:340-352."""
-    if name == "Attention-GRU":
-        raise NotImplementedError("AttentionGRUModel is not built on the HIP path (no GRU kernel); 'LSTM' and 'BP' are")
     if name not in BASELINE_MODELS:
-        raise ValueError(f"Unknown baseline model: {name}. Choose from {list(BASELINE_MODELS) + ['Attention-GRU']}")
+        raise ValueError(f"Unknown baseline model: {name}. Choose from {list(BASELINE_MODELS)}")
     return BASELINE_MODELS[name](config)

@@ -59,6 +59,8 @@ def lib():
         L.sf_wgrad4x4s2_workspace_bytes.restype = ctypes.c_size_t
         L.sf_enc1_bwd_workspace_bytes.restype = ctypes.c_size_t
         L.sf_date_image_metrics_workspace_bytes.restype = ctypes.c_size_t
+        L.sf_gru_save_floats.restype = ctypes.c_size_t
+        L.sf_attn_save_floats.restype = ctypes.c_size_t
         _lib = L
     return _lib
 
@@ -72,7 +74,8 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
            "sf_bce_logits", "sf_adam", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
            "sf_gather_frames", "sf_date_image_metrics", "sf_date_image_metrics_workspace_bytes", "sf_bn_relu_fwd",
-           "sf_relu_dropout_fwd", "sf_relu_dropout_bwd"]
+           "sf_relu_dropout_fwd", "sf_relu_dropout_bwd", "sf_gru_save_floats", "sf_gru_fwd", "sf_gru_bwd",
+           "sf_attn_save_floats", "sf_attn_fwd", "sf_attn_bwd"]
 
 
 def _check(rc: int, who: str):
@@ -706,6 +709,45 @@ def lstm_bwd(x, dy, ws, dws, save, L, p_drop, seed):
     _check(lib().sf_lstm_bwd(_p(x), _p(dy), _p(dx), _ptr_array(ws), _ptr_array(dws), _p(save), B, T, H, L,
                              _c_f(p_drop), ctypes.c_ulonglong(seed), _stream()), "sf_lstm_bwd")
     return dx
+
+
+def gru_fwd(x, ws, L, p_drop, seed, need_save: bool):
+    """x f32 [B,T,H] -> (output sequence [B,T,H], save or None)."""
+    _dev(x, *ws, dtypes=[torch.float32] * (1 + len(ws)))
+    B, T, H = x.shape
+    y = torch.empty_like(x)
+    save = torch.empty(B * int(lib().sf_gru_save_floats(T, H, L)), device=x.device, dtype=torch.float32) if need_save else None
+    _check(lib().sf_gru_fwd(_p(x), _p(y), _ptr_array(ws), _p(save), B, T, H, L, _c_f(p_drop), ctypes.c_ulonglong(seed),
+                            _stream()), "sf_gru_fwd")
+    return y, save
+
+
+def gru_bwd(x, dy, ws, dws, save, L, p_drop, seed):
+    _dev(x, dy, save, *ws, *dws)
+    B, T, H = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().sf_gru_bwd(_p(x), _p(dy), _p(dx), _ptr_array(ws), _ptr_array(dws), _p(save), B, T, H, L,
+                            _c_f(p_drop), ctypes.c_ulonglong(seed), _stream()), "sf_gru_bwd")
+    return dx
+
+
+def attn_fwd(g, ws, need_save: bool):
+    """g f32 [B,T,H], ws = [Wq, bq, Wk, bk, Wv, bv] -> (context [B,H], save or None)."""
+    _dev(g, *ws, dtypes=[torch.float32] * 7)
+    B, T, H = g.shape
+    out = torch.empty((B, H), device=g.device, dtype=torch.float32)
+    save = torch.empty(B * int(lib().sf_attn_save_floats(T, H)), device=g.device, dtype=torch.float32) if need_save else None
+    _check(lib().sf_attn_fwd(_p(g), _p(out), _ptr_array(ws), _p(save), B, T, H, _stream()), "sf_attn_fwd")
+    return out, save
+
+
+def attn_bwd(g, dout, ws, dws, save):
+    _dev(g, dout, save, *ws, *dws)
+    B, T, H = g.shape
+    dg = torch.empty_like(g)
+    _check(lib().sf_attn_bwd(_p(g), _p(dout), _p(dg), _ptr_array(ws), _ptr_array(dws), _p(save), B, T, H, _stream()),
+           "sf_attn_bwd")
+    return dg
 
 
 # ------------------------------------------------------------------------------ losses / optimiser

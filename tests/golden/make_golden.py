@@ -58,7 +58,7 @@ def zero_dropout(model):
             m.p = 0.0
         if isinstance(m, torch.nn.MultiheadAttention):
             m.dropout = 0.0
-        if isinstance(m, torch.nn.LSTM):
+        if isinstance(m, (torch.nn.LSTM, torch.nn.GRU)):
             m.dropout = 0.0
 
 
@@ -493,7 +493,7 @@ def gen_baselines():
            "data": {"image_size": [64, 64], "upscale_factor": 2, "window_size": 5}}
     x = G.gold_tensor("base/x", (2, 5, 3, 64, 64))
     u = G.gold_tensor("base/u", (2, 1, 128, 128))
-    for name in ("LSTM", "BP"):
+    for name in ("LSTM", "BP", "Attention-GRU"):
         m = build_baseline_model(name, cfg)
         load_gold(m, "base_" + name)
         zero_dropout(m)

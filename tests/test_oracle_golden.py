@@ -395,7 +395,7 @@ def test_dataset_restatement(oracle, tag):
 
 
 def baseline_shapes(name, cin=3, hidden=32, layers=2, window=5):
-    """state_dict shapes of PureLSTMModel / PureBPModel, restated from src/model/baseline_models.py."""
+    """state_dict shapes of the baseline models, restated from src/model/baseline_models.py."""
     s = {}
     ch = [cin, 32, 32, 16]
     for li, i in enumerate((0, 3, 6)):
@@ -403,11 +403,15 @@ def baseline_shapes(name, cin=3, hidden=32, layers=2, window=5):
         for nm in ("weight", "bias", "running_mean", "running_var"):
             s[f"reducer.encoder.{i + 1}.{nm}"] = (ch[li + 1],)
         s[f"reducer.encoder.{i + 1}.num_batches_tracked"] = ()
-    if name == "LSTM":
+    if name in ("LSTM", "Attention-GRU"):
+        rnn, gates = ("lstm", 4) if name == "LSTM" else ("gru", 3)
         s["input_proj.weight"], s["input_proj.bias"] = (hidden, 1024), (hidden,)
         for l in range(layers):
-            s[f"lstm.weight_ih_l{l}"], s[f"lstm.weight_hh_l{l}"] = (4 * hidden, hidden), (4 * hidden, hidden)
-            s[f"lstm.bias_ih_l{l}"], s[f"lstm.bias_hh_l{l}"] = (4 * hidden,), (4 * hidden,)
+            s[f"{rnn}.weight_ih_l{l}"], s[f"{rnn}.weight_hh_l{l}"] = (gates * hidden, hidden), (gates * hidden, hidden)
+            s[f"{rnn}.bias_ih_l{l}"], s[f"{rnn}.bias_hh_l{l}"] = (gates * hidden,), (gates * hidden,)
+        if name == "Attention-GRU":
+            for nm in ("query", "key", "value"):
+                s[f"attention.{nm}.weight"], s[f"attention.{nm}.bias"] = (hidden, hidden), (hidden,)
         head_in = hidden
     else:
         dims = [window * 1024, 4 * hidden, 4 * hidden, 2 * hidden]
@@ -420,7 +424,7 @@ def baseline_shapes(name, cin=3, hidden=32, layers=2, window=5):
     return s
 
 
-@pytest.mark.parametrize("name", ["LSTM", "BP"])
+@pytest.mark.parametrize("name", ["LSTM", "BP", "Attention-GRU"])
 def test_baseline_models_restatement(name):
     g = golden("baselines")
     shapes = baseline_shapes(name)

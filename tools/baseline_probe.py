@@ -13,7 +13,7 @@ cfg = {"model": {"input_channels": 10, "hidden_dim": 64, "num_layers": 2},
        "data": {"image_size": [256, 256], "upscale_factor": 1, "window_size": 5}}
 B = 32
 x = torch.randn(B, 5, 10, 256, 256, device="cuda")
-for name in ("LSTM", "BP"):
+for name in ("LSTM", "BP", "Attention-GRU"):
     m = sf.build_baseline_model(name, cfg).cuda().train()
     for amp in (False, True):
         def step():
@@ -30,4 +30,4 @@ for name in ("LSTM", "BP"):
             step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 20
-        print(f"{name:5s} {'bf16' if amp else 'f32 '}  {dt * 1e3:7.2f} ms / step   {B / dt:8.0f} samples/s", flush=True)
+        print(f"{name:13s} {'bf16' if amp else 'f32 '}  {dt * 1e3:7.2f} ms / step   {B / dt:8.0f} samples/s", flush=True)
