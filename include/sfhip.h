@@ -131,7 +131,13 @@ int sf_pack_conv_weight(const float* w, void* out, int dtype, int O, int I, int 
 int sf_cast(const float* in, void* out, int dtype, long long n, void* stream);
 
 /* ---- BatchNorm / activation / pooling (src/model/cnn_encoder.py:54-61,69,88-91; src/model/gan.py:32-33) */
-/* Per-channel sum and sum of squares of x[M][C] into ws (2*C doubles, zeroed here). */
+/* Reduction workspaces of this group: SF_BN_WS_DOUBLES(C) doubles.  Every workgroup writes its
+ * partial sums to a row of its own and a fold kernel adds the rows in a fixed order into the first
+ * 2*C doubles, which is what the consumers (sf_bn_finalize, sf_bn_bwd_apply) read: no atomics, no
+ * zeroing, bit-reproducible sums. */
+#define SF_BN_WS_PARTS 1024
+#define SF_BN_WS_DOUBLES(C) (2 * (size_t)(C) * (1 + SF_BN_WS_PARTS))
+/* Per-channel sum and sum of squares of x[M][C] into ws[0..2C). */
 int sf_bn_stats(const void* x, int dtype, long long M, int C, double* ws, void* stream);
 /* training=1: batch statistics from ws (biased var for normalisation; running stats updated
  * with momentum and the unbiased var).  training=0: running statistics.
@@ -158,8 +164,8 @@ int sf_bn_relu_fwd(const void* x, int dtype, const float* scale, const float* sh
  * BatchNorm backward fused with the backward of what follows it.  mode 0: ReLU+maxpool2x2
  * (dy = gradient wrt the pooled map, NHWC dtype); mode 1: ReLU+adaptive avgpool (dy = NHWC
  * dtype [N,OH,OW,C]); mode 2: LeakyReLU(0.2) (dy NHWC dtype); mode 3: ReLU, no pooling (dy NHWC dtype).
- * Pass 1 (sf_bn_bwd_reduce) accumulates sum(dz) and sum(dz*xhat) per channel into ws
- * (2*C doubles, zeroed here); pass 2 (sf_bn_bwd_apply) writes
+ * Pass 1 (sf_bn_bwd_reduce) leaves sum(dz) and sum(dz*xhat) per channel in ws[0..2C)
+ * (ws: SF_BN_WS_DOUBLES(C) doubles); pass 2 (sf_bn_bwd_apply) writes
  * dx = scale*(dz - mean(dz) - xhat*mean(dz*xhat)) (training) or scale*dz (eval) and
  * dgamma = sum(dz*xhat), dbeta = sum(dz).
  */
@@ -172,7 +178,7 @@ int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* dy, int dy_d
                     const float* invstd, const float* gamma, const double* ws, int training,
                     void* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, int Creal,
                     int OH, int OW, void* stream);
-/* out[c] = sum_m x[m][c] (bias gradients); out f32 [Creal]; ws: C doubles (zeroed here). */
+/* out[c] = sum_m x[m][c] (bias gradients); out f32 [Creal]; ws: SF_BN_WS_DOUBLES(C) doubles. */
 int sf_channel_sum(const void* x, int dtype, long long M, int C, int Creal, float* out, double* ws,
                    void* stream);
 

@@ -66,7 +66,7 @@ class ReducerFn(torch.autograd.Function):
             M = N * oh * ow
             ws = None
             if training:
-                ws = torch.empty(2 * K, device=x.device, dtype=torch.float64)
+                ws = ops.bn_ws(K, x.device)
                 ops.bn_stats(z, M, K, ws)
             st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, training)
             saved.append((a, z, st, (h, w)))

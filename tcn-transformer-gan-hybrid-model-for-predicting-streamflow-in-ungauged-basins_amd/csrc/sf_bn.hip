@@ -127,12 +127,43 @@ __global__ __launch_bounds__(BT) void colsum_kernel(const T* __restrict__ x, uns
     }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
+        // this block's row of the partial-sum slab (row 0 of ws is the folded result)
+        double* row = ws + (size_t)(1 + blockIdx.x) * ((SQ ? 2 : 1) * C);
         const double ts = group_sum(s[e], m, sm);
-        if ((int)threadIdx.x < m.G) unsafeAtomicAdd(&ws[threadIdx.x * EPC + e], ts);
+        if ((int)threadIdx.x < m.G) row[threadIdx.x * EPC + e] = ts;
         if (SQ) {
             const double tq = group_sum(q[e], m, sm);
-            if ((int)threadIdx.x < m.G) unsafeAtomicAdd(&ws[C + threadIdx.x * EPC + e], tq);
+            if ((int)threadIdx.x < m.G) row[C + threadIdx.x * EPC + e] = tq;
         }
+    }
+}
+
+// ws[j] = sum over the `parts` slab rows ws[(1 + p) * n + j], j < n: 16 columns x 16 row groups per
+// block, eight loads in flight, fixed order (the sums are bit-reproducible).
+__global__ __launch_bounds__(256) void ws_fold_kernel(double* __restrict__ ws, int n, int parts) {
+    __shared__ double sm[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + cl;
+    const int jj = j < n ? j : n - 1;
+    const double* slab = ws + n;
+    double a = 0.0;
+    for (int p = rg; p < parts; p += 16 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int pp = p + 16 * u;
+            v[u] = slab[(size_t)(pp < parts ? pp : parts - 1) * n + jj];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += (p + 16 * u < parts) ? v[u] : 0.0;
+    }
+    sm[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && j < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += sm[g][cl];
+        ws[j] = t;
     }
 }
 
@@ -473,10 +504,11 @@ __global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(BnBwd a, double* __re
     }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
+        double* row = ws + (size_t)(1 + blockIdx.x) * (2 * a.C);   // this block's row of the partial-sum slab
         const double t1 = group_sum(s1[e], m, sm);
-        if ((int)threadIdx.x < m.G) unsafeAtomicAdd(&ws[threadIdx.x * EPC + e], t1);
+        if ((int)threadIdx.x < m.G) row[threadIdx.x * EPC + e] = t1;
         const double t2 = group_sum(s2[e], m, sm);
-        if ((int)threadIdx.x < m.G) unsafeAtomicAdd(&ws[a.C + threadIdx.x * EPC + e], t2);
+        if ((int)threadIdx.x < m.G) row[a.C + threadIdx.x * EPC + e] = t2;
     }
 }
 
@@ -534,9 +566,8 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply_kernel(BnBwd a, const double*
 
 // rows per workgroup for `items` rows on at most `cap` workgroups, a multiple of `step`
 struct Split { unsigned per; int grid; };
-// min_batches > 1 (reductions): a workgroup gets at least that many batches, so small tensors
-// use few workgroups -- each workgroup of a reduction ends with one same-address atomic per
-// channel, ~0.1 us apiece and serialised.
+// min_batches > 1 (reductions): a workgroup gets at least that many batches, so that the
+// block-level fold and the slab row it writes are amortised over enough streamed rows.
 inline Split split_rows(long long items, int step, int cap, int min_batches = 1) {
     long long grid = (items + (long long)step * min_batches - 1) / ((long long)step * min_batches);
     if (grid > cap) grid = cap;
@@ -573,13 +604,9 @@ int check_chunked(const char* who, int dtype, int C) {
 static int colsum_launch(const char* who, bool sq, const void* x, int dtype, long long M, int C, double* ws,
                          hipStream_t s) {
     SF_REQUIRE(M < 0x7fffffffLL, "%s: too many rows", who);
-    if (hipMemsetAsync(ws, 0, sizeof(double) * (sq ? 2 : 1) * C, s) != hipSuccess) {
-        sf_set_error("%s: memset failed", who);
-        return SF_ELAUNCH;
-    }
     const int epc = dtype == SF_BF16 ? 8 : 4;
     const int rpp = BT / (C / epc);
-    const Split sp = split_rows(M, rpp * 8, 512, 16);
+    const Split sp = split_rows(M, rpp * 8, SF_BN_WS_PARTS, 4);
     if (sq) {
         DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, true>), dim3(sp.grid), dim3(BT), 0, s, (const T*)x,
                                              (unsigned)M, sp.per, C, ws));
@@ -587,6 +614,8 @@ static int colsum_launch(const char* who, bool sq, const void* x, int dtype, lon
         DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, false>), dim3(sp.grid), dim3(BT), 0, s, (const T*)x,
                                              (unsigned)M, sp.per, C, ws));
     }
+    const int n = (sq ? 2 : 1) * C;
+    hipLaunchKernelGGL(ws_fold_kernel, dim3((n + 15) / 16), dim3(256), 0, s, ws, n, sp.grid);
     return SF_OK;
 }
 
@@ -675,14 +704,14 @@ extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* 
                                 int W, int C, int Creal, int OH, int OW, void* stream) {
     BnBwd a;
     const int grid = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, scale, N, H, W, C, Creal, OH, OW, 1, dtype,
-                                dy_dtype, 512);
+                                dy_dtype, SF_BN_WS_PARTS);
     if (grid < 0) return grid;
     SF_REQUIRE(ws, "sf_bn_bwd_reduce: null workspace");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { sf_set_error("sf_bn_bwd_reduce: memset failed"); return SF_ELAUNCH; }
 #define RED(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), dim3(grid), dim3(BT), 0, s, a, ws))
     if (mode == 0) { RED(0); } else if (mode == 1) { RED(1); } else { RED(2); }   // modes 2 and 3 differ in a.slope only
 #undef RED
+    hipLaunchKernelGGL(ws_fold_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, 2 * C, grid);
     SF_LAUNCH_CHECK("sf_bn_bwd_reduce");
     return SF_OK;
 }

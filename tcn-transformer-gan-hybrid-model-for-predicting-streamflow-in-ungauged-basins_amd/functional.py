@@ -90,7 +90,7 @@ class EncoderFn(torch.autograd.Function):
             ops.conv3x3(a, wp, z, Kpad, flop_c=wt.shape[1], flop_k=K)
             ws = None
             if training:
-                ws = torch.empty(2 * Kpad, device=x.device, dtype=torch.float64)
+                ws = ops.bn_ws(Kpad, x.device)
                 ops.bn_stats(z, M, Kpad, ws)
             st = ops.bn_finalize(ws, M, Kpad, K, gamma.detach(), beta.detach(), rm, rv, training)
             saved.append((a, z, st, (h, w), None))
@@ -415,7 +415,7 @@ class DiscriminatorFn(torch.autograd.Function):
             z = torch.empty((N, oh, ow, K), device=x.device, dtype=cdtype)
             ops.conv_fprop(y, wp, z, _s2_geom(N, ih, iw, C, oh, ow), K, bias=b.detach().contiguous())
             M = N * oh * ow
-            ws = torch.empty(2 * K, device=x.device, dtype=torch.float64)
+            ws = ops.bn_ws(K, x.device)
             ops.bn_stats(z, M, K, ws)
             st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, True)
             y = ops.bn_lrelu_fwd(z, st)

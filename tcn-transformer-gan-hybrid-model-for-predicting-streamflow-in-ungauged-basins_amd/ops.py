@@ -131,6 +131,13 @@ FORCE_GENERIC_CONV = False
 # Launch timing for the benchmark's roofline line: tags listed in TIMED get a HIP event pair
 # recorded on the launch stream around each sf_gemm call carrying that tag.
 LOSS_WS_DOUBLES = 4096  # SF_LOSS_WS_DOUBLES of include/sfhip.h
+BN_WS_PARTS = 1024      # SF_BN_WS_PARTS
+
+
+def bn_ws(C: int, device) -> torch.Tensor:
+    """Workspace of the BatchNorm / channel-sum reductions: SF_BN_WS_DOUBLES(C) doubles; the folded
+    sums end up in the first 2*C."""
+    return torch.empty(2 * C * (1 + BN_WS_PARTS), device=device, dtype=torch.float64)
 TIMED: dict = {}
 
 
@@ -358,6 +365,8 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ------------------------------------------------------------------------------ batch norm family
 def bn_stats(x: torch.Tensor, M: int, C: int, ws: torch.Tensor):
     _dev(x, ws)
+    if ws.dtype != torch.float64 or ws.numel() < 2 * C * (1 + BN_WS_PARTS):
+        raise RuntimeError("bn_stats: the workspace must come from ops.bn_ws(C, device)")
     _check(lib().sf_bn_stats(_p(x), code_of(x.dtype), _c_ll(M), C, _p(ws), _stream()), "sf_bn_stats")
 
 
@@ -458,7 +467,7 @@ def bn_backward(mode, x, dy, st, gamma, Creal, training, OH=0, OW=0):
     """Returns (dx, dgamma, dbeta); see sf_bn_bwd_reduce / sf_bn_bwd_apply."""
     _dev(x, dy, st, gamma)
     N, H, W, C = x.shape
-    ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+    ws = bn_ws(C, x.device)
     c = code_of(x.dtype)
     _check(lib().sf_bn_bwd_reduce(mode, _p(x), c, _p(dy), code_of(dy.dtype), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
                                   _p(ws), N, H, W, C, Creal, OH, OW, _stream()), "sf_bn_bwd_reduce")
@@ -475,7 +484,7 @@ def channel_sum(x: torch.Tensor, Creal: int) -> torch.Tensor:
     _dev(x)
     C = x.shape[-1]
     out = torch.empty(Creal, device=x.device, dtype=torch.float32)
-    ws = torch.empty(C, device=x.device, dtype=torch.float64)
+    ws = bn_ws(C, x.device)
     _check(lib().sf_channel_sum(_p(x), code_of(x.dtype), _c_ll(x.numel() // C), C, Creal, _p(out), _p(ws), _stream()),
            "sf_channel_sum")
     return out

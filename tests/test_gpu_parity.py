@@ -628,8 +628,9 @@ def test_enc1_fused_layer_against_separate_kernels(sf):
         z = torch.empty(N, H, W, K, device=DEV, dtype=torch.bfloat16)
         ops.conv3x3(x, wp, z, K)
         M = N * H * W
-        ws_ref = torch.empty(2 * K, device=DEV, dtype=torch.float64)
+        ws_ref = ops.bn_ws(K, DEV)
         ops.bn_stats(z, M, K, ws_ref)
+        ws_ref = ws_ref[:2 * K]
         ws = torch.empty(2 * K, device=DEV, dtype=torch.float64)
         ops.enc1_stats(x, wp, K, ws)
         assert float((ws[K:] - ws_ref[K:]).abs().max() / ws_ref[K:].abs().max()) < 2e-4
