@@ -403,6 +403,12 @@ int sf_attn_fwd(const float* g, float* out, const float* const* w, float* save, 
                 void* stream);
 int sf_attn_bwd(const float* g, const float* dout, float* dg, const float* const* w,
                 float* const* dw, const float* save, int B, int T, int H, void* stream);
+/* Four weight-matrix gradients over n tokens in one launch: out[q] f32 [I[q]][J[q]] =
+ * sum_t g[q][t][:]^T a[q][t][:] with g[q] f32 [n][I[q]] (per-token gradients) and a[q] f32 [n][J[q]]
+ * (saved activations): the in_proj, out_proj, linear1 and linear2 weight gradients of a
+ * TransformerEncoderLayer (src/model/transformer_module.py:83-91).  Sizes multiples of 64. */
+int sf_token_outer4(const float* const* g, const float* const* a, float* const* out, const int* I,
+                    const int* J, int n, void* stream);
 
 #ifdef __cplusplus
 }

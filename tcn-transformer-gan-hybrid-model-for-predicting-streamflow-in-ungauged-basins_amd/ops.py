@@ -75,7 +75,7 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_bce_logits", "sf_adam", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
            "sf_gather_frames", "sf_date_image_metrics", "sf_date_image_metrics_workspace_bytes", "sf_bn_relu_fwd",
            "sf_relu_dropout_fwd", "sf_relu_dropout_bwd", "sf_gru_save_floats", "sf_gru_fwd", "sf_gru_bwd",
-           "sf_attn_save_floats", "sf_attn_fwd", "sf_attn_bwd"]
+           "sf_attn_save_floats", "sf_attn_fwd", "sf_attn_bwd", "sf_token_outer4"]
 
 
 def _check(rc: int, who: str):
@@ -668,6 +668,11 @@ def transformer_layer_bwd(x, dy, ws, dws, save, nhead, p_drop, seed):
     g_qkv, g_sa = gtok[: n * 3 * D], gtok[n * 3 * D: n * 4 * D]
     g_z, g_ff = gtok[n * 4 * D: n * 4 * D + n * Fd], gtok[n * (4 * D + Fd):]
     xin = x.reshape(-1)
+    if D % 64 == 0 and Fd % 64 == 0:
+        gs, acts, outs = [g_qkv, g_sa, g_z, g_ff], [xin, saved(2, D), saved(5, D), saved(6, Fd)], [dws[0], dws[2], dws[4], dws[6]]
+        _check(lib().sf_token_outer4(_ptr_array(gs), _ptr_array(acts), _ptr_array(outs), (_c_int * 4)(3 * D, D, Fd, D),
+                                     (_c_int * 4)(D, D, D, Fd), n, _stream()), "sf_token_outer4")
+        return dx
     linear_gemm(g_qkv, xin, dws[0], 3 * D, D, n, 3 * D, D, D, True, True, OUT_IJ)
     linear_gemm(g_sa, saved(2, D), dws[2], D, D, n, D, D, D, True, True, OUT_IJ)
     linear_gemm(g_z, saved(5, D), dws[4], Fd, D, n, Fd, D, D, True, True, OUT_IJ)

@@ -722,3 +722,35 @@ def test_colsum_f32_shapes(sf):
         x = torch.randn(M, C, device=DEV)
         got = sf.ops.colsum_f32(x)
         close(got, x.double().sum(0).cpu().numpy(), 1e-6)
+
+
+def test_token_outer4_against_matmul(sf):
+    """The one-launch weight gradients of an encoder layer (sf_token_outer4) against g^T a in
+    float64, at the bench shape (160 tokens) and with a token count spanning several LDS chunks;
+    and the whole layer backward with D = 128 against the GEMM path's result at D = 16 being
+    covered by the golden temporal tests."""
+    import ctypes
+    ops = sf.ops
+    torch.manual_seed(2)
+    D, Fd = 128, 512
+    for n in (160, 300, 7):
+        I, J = [3 * D, D, Fd, D], [D, D, D, Fd]
+        gs = [torch.randn(n, i, device=DEV) for i in I]
+        acts = [torch.randn(n, j, device=DEV) for j in J]
+        outs = [torch.empty(i, j, device=DEV) for i, j in zip(I, J)]
+        rc = ops.lib().sf_token_outer4(ops._ptr_array(gs), ops._ptr_array(acts), ops._ptr_array(outs),
+                                       (ctypes.c_int * 4)(*I), (ctypes.c_int * 4)(*J), n, ops._stream())
+        assert rc == 0
+        for g, a, o in zip(gs, acts, outs):
+            close(o, (g.double().t() @ a.double()).cpu().numpy(), 1e-5)
+    # a Transformer stack at the bench width (its backward runs through the new kernel) against
+    # autograd through the CPU restatement
+    m = sf.TransformerModule(1024, 128, num_layers=2, num_heads=4, dropout=0.0).to(DEV).train()
+    x = torch.randn(4, 5, 1024, device=DEV)
+    u = torch.randn(4, 128, device=DEV)
+    (m(x) * u).sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "pe" not in k)
+          for k, v in m.state_dict().items()}
+    (O.transformer_forward(x.cpu(), sd, prefix="", num_layers=2, nhead=4) * u.cpu()).sum().backward()
+    for k, p in m.named_parameters():
+        close(p.grad, sd[k].grad.numpy(), 2e-4)
