@@ -71,6 +71,9 @@ typedef struct sf_gemm_desc {
     int act;                /* 0 none, 1 ReLU, 2 LeakyReLU(0.2); after bias; nsplit == 1 only */
     int aux_mode;           /* 0 none; 1: out *= (aux > 0); 2: out *= (aux > 0 ? 1 : 0.2) */
     sf_conv_geom g;
+    long long split_stride; /* with nsplit > 1: 0 = atomic accumulation into out; > 0 = split s stores its
+                             * partial result at out + s*split_stride floats with plain stores (all nsplit
+                             * slices are defined on return; the caller sums them, e.g. sf_colsum_f32) */
 } sf_gemm_desc;
 
 int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, const float* bias,

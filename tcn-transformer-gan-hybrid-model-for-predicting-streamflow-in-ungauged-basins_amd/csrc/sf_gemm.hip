@@ -68,6 +68,7 @@ struct KParams {
     long long I, J, R, lda, ldb, ldo;
     int niters, iters_per_split, nsplit, nsplit_req, ni_tiles, nj_tiles;
     int b_gather, out_mode, out_dtype, act, aux_mode, atomic;
+    long long split_stride;   // > 0: split s stores its partial result at out + s * split_stride (no atomics)
     unsigned long long dy_pack, dx_pack;  // tap offsets + 8, 4 bits per tap
     sf_conv_geom g;
 };
@@ -311,6 +312,7 @@ __device__ __forceinline__ void gemm_body(const KParams& p, const int block_id, 
     const int h = lane >> 5;
     const bool atomic = p.atomic != 0;
     const bool add_bias = p.bias != nullptr && split == 0;
+    void* const outp = p.split_stride > 0 ? (void*)(reinterpret_cast<float*>(p.out) + (long long)split * p.split_stride) : p.out;
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const long long j = j0 + wj * 64 + b * 32 + (lane & 31);
@@ -344,7 +346,7 @@ __device__ __forceinline__ void gemm_body(const KParams& p, const int block_id, 
                         for (int e = 0; e < 4; ++e) v[e] += p.bias[i + e];
                     }
                     if (atomic) {
-                        float* o = reinterpret_cast<float*>(p.out) + off;
+                        float* o = reinterpret_cast<float*>(outp) + off;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
                     } else {
@@ -365,24 +367,24 @@ __device__ __forceinline__ void gemm_body(const KParams& p, const int block_id, 
                             }
                         }
                         if (p.out_dtype == SF_F32) {
-                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + off) =
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + off) =
                                 make_float4(v[0], v[1], v[2], v[3]);
                         } else {
                             Vec4<bf16> o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o.set(e, v[e]);
-                            o.store(reinterpret_cast<bf16*>(p.out) + off);
+                            o.store(reinterpret_cast<bf16*>(outp) + off);
                         }
                     }
                 } else if (p.out_mode == SF_OUT_IJ) {
-                    float* o = reinterpret_cast<float*>(p.out);
+                    float* o = reinterpret_cast<float*>(outp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const long long off = (i + e) * p.ldo + j;
                         if (atomic) unsafeAtomicAdd(o + off, v[e]); else o[off] = v[e];
                     }
                 } else {  // SF_OUT_OIHW (always accumulated atomically)
-                    float* o = reinterpret_cast<float*>(p.out);
+                    float* o = reinterpret_cast<float*>(outp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (i + e >= p.ldo) continue;  // ldo = real output-channel count of the OIHW tensor
@@ -444,6 +446,14 @@ int launch_one(const KParams& q, hipStream_t s) {
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         sf_set_error("sf_gemm: bad grid (%lld blocks)", nblk);
         return SF_EINVAL;
+    }
+    if (p.split_stride > 0 && p.nsplit < p.nsplit_req) {
+        // fewer slices than asked for have work: the caller sums all nsplit_req of them
+        if (hipMemsetAsync(reinterpret_cast<float*>(p.out) + (long long)p.nsplit * p.split_stride, 0,
+                           sizeof(float) * (size_t)(p.nsplit_req - p.nsplit) * p.split_stride, s) != hipSuccess) {
+            sf_set_error("sf_gemm: memset of the unused split slices failed");
+            return SF_ELAUNCH;
+        }
     }
     hipLaunchKernelGGL((gemm_kernel<T, A_KM, B_KM, TI, BK>), dim3((unsigned)nblk), dim3(NTHREADS), lds, s, p);
     SF_LAUNCH_CHECK("sf_gemm");
@@ -528,7 +538,8 @@ static int fill_kparams(const sf_gemm_desc* d, const void* A, const void* B, con
         }
     }
     // a requested split keeps its accumulate-into-out semantics even when it degenerates to one slice
-    p.atomic = (d->nsplit > 1 || d->out_mode == SF_OUT_OIHW) ? 1 : 0;
+    p.split_stride = d->nsplit > 1 ? d->split_stride : 0;
+    p.atomic = ((d->nsplit > 1 && p.split_stride == 0) || d->out_mode == SF_OUT_OIHW) ? 1 : 0;
     return SF_OK;
 }
 

@@ -144,6 +144,20 @@ class EncoderFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------ 262144-wide Linear
+def _split_gemm(A, B, I, J, R, lda, ldb, ldo, a_km, nsplit, bias):
+    """out f32 [J][I] = B[J][R] . A^T (+ bias) with the reduction split over nsplit workgroup
+    slices: every slice stores its partial result to a row of its own and sf_colsum_f32 adds the
+    rows (fixed order, no atomics: with 256 slices the atomic epilogues of this shape cost more
+    than the products)."""
+    if nsplit <= 1:
+        out = torch.empty((J, I), device=A.device, dtype=torch.float32)
+        ops.linear_gemm(A, B, out, I, J, R, lda, ldb, ldo, a_km, False, ops.OUT_JI, 1, bias)
+        return out
+    slab = torch.empty((nsplit, J * I), device=A.device, dtype=torch.float32)
+    ops.linear_gemm(A, B, slab, I, J, R, lda, ldb, ldo, a_km, False, ops.OUT_JI, nsplit, bias, split_stride=J * I)
+    return ops.colsum_f32(slab).view(J, I)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b for the two skinny, weight-bandwidth-bound Linear layers
     (src/model/transformer_module.py:73 / src/model/lstm_module.py:36, src/model/__init__.py:92-95)."""
@@ -158,9 +172,7 @@ class LinearFn(torch.autograd.Function):
         Wt = ops.cast(W.detach().contiguous(), cdtype)
         bk = 32 if cdtype == torch.bfloat16 else 16
         nsplit = max(1, min(256, K // (bk * 16)))
-        y = (torch.zeros if nsplit > 1 else torch.empty)((M, Nf), device=x.device, dtype=torch.float32)
-        ops.linear_gemm(Wt, xt, y, Nf, M, K, K, K, Nf, False, False, ops.OUT_JI, nsplit,
-                        b.detach().contiguous() if b is not None else None)
+        y = _split_gemm(Wt, xt, Nf, M, K, K, K, Nf, False, nsplit, b.detach().contiguous() if b is not None else None)
         ctx.save_for_backward(xt, Wt)
         ctx.dims = (M, K, Nf, bk)
         ctx.has_bias = b is not None
@@ -175,8 +187,7 @@ class LinearFn(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             nsplit = max(1, min(256, Nf // (bk * 16)))
-            dx = (torch.zeros if nsplit > 1 else torch.empty)((M, K), device=dy.device, dtype=torch.float32)
-            ops.linear_gemm(Wt, dyt, dx, K, M, Nf, K, Nf, K, True, False, ops.OUT_JI, nsplit)
+            dx = _split_gemm(Wt, dyt, K, M, Nf, K, Nf, K, True, nsplit, None)
         if ctx.needs_input_grad[1]:
             dW = torch.empty((Nf, K), device=dy.device, dtype=torch.float32)
             ops.linear_gemm(dyt, xt, dW, Nf, K, M, Nf, K, K, True, True, ops.OUT_IJ, 1)

@@ -38,7 +38,7 @@ class GemmDesc(ctypes.Structure):
                 ("I", _c_ll), ("J", _c_ll), ("R", _c_ll),
                 ("lda", _c_ll), ("ldb", _c_ll), ("ldo", _c_ll),
                 ("nsplit", _c_int), ("out_mode", _c_int), ("out_dtype", _c_int), ("act", _c_int),
-                ("aux_mode", _c_int), ("g", ConvGeom)]
+                ("aux_mode", _c_int), ("g", ConvGeom), ("split_stride", _c_ll)]
 
 
 _lib = None
@@ -316,8 +316,11 @@ def conv_wgrad(x, dout, dw, geom: ConvGeom, K: int, nsplit: Optional[int] = None
     gemm(d, dout, x, dw, tag=tag)
 
 
-def linear_gemm(A, B, out, I, J, R, lda, ldb, ldo, a_km, b_km, out_mode, nsplit=1, bias=None):
+def linear_gemm(A, B, out, I, J, R, lda, ldb, ldo, a_km, b_km, out_mode, nsplit=1, bias=None, split_stride=0):
+    """split_stride > 0 (with nsplit > 1): `out` is a slab of nsplit partial results split_stride
+    floats apart (plain stores, to be summed by the caller); 0: atomic accumulation into a zeroed out."""
     d = GemmDesc()
+    d.split_stride = split_stride
     d.dtype = code_of(A.dtype)
     d.a_kmajor, d.b_kmajor, d.b_gather = int(a_km), int(b_km), 0
     d.I, d.J, d.R, d.lda, d.ldb, d.ldo = I, J, R, lda, ldb, ldo
