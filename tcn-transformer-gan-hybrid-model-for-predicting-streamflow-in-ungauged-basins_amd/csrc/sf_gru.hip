@@ -19,7 +19,8 @@ __device__ __forceinline__ float dot4(const float* __restrict__ wrow, const floa
     float a = 0.f;
     for (int d = 0; d < n; d += 4) {
         const float4 w = *reinterpret_cast<const float4*>(wrow + d);
-        a += w.x * v[d] + w.y * v[d + 1] + w.z * v[d + 2] + w.w * v[d + 3];
+        const float4 x = *reinterpret_cast<const float4*>(v + d);   // v is 16-byte aligned (LDS rows of H % 4 == 0 floats)
+        a += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
     }
     return a;
 }

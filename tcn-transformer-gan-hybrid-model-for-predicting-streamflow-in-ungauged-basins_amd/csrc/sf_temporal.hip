@@ -39,8 +39,8 @@ __device__ __forceinline__ void dot_row_tokens(const float* __restrict__ wrow, c
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t)
                     if (t < T) {
-                        const float* vv = v + t * ldv + d + 4 * k;
-                        acc[t] += w[k].x * vv[0] + w[k].y * vv[1] + w[k].z * vv[2] + w[k].w * vv[3];
+                        const float4 vv = *reinterpret_cast<const float4*>(v + t * ldv + d + 4 * k);   // one 16-byte LDS read
+                        acc[t] += w[k].x * vv.x + w[k].y * vv.y + w[k].z * vv.z + w[k].w * vv.w;
                     }
             }
         }
@@ -51,7 +51,8 @@ __device__ __forceinline__ float dot_row(const float* __restrict__ wrow, const f
     float a = 0.f;
     for (int d = 0; d < n; d += 4) {
         const float4 w = *reinterpret_cast<const float4*>(wrow + d);
-        a += w.x * v[d] + w.y * v[d + 1] + w.z * v[d + 2] + w.w * v[d + 3];
+        const float4 x = *reinterpret_cast<const float4*>(v + d);   // v is 16-byte aligned (LDS rows of H % 4 == 0 floats)
+        a += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
     }
     return a;
 }
@@ -264,17 +265,34 @@ __device__ __forceinline__ void tok_matmul(const float* __restrict__ in, int ldi
                     const int o = ob + k < o1 ? ob + k : o0;
                     w[k] = *reinterpret_cast<const float4*>(wp + (size_t)o * ldw);
                 }
+                // the tokens' gradient values of these NL rows: two 16-byte LDS reads per token when the
+                // batch is whole and aligned (scalar reads of the same values bound this loop before)
+                float gv[MAXT][NL];
+                const bool whole = ob + NL <= o1 && ((ob | ldin) & 3) == 0;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    if (t < T) {
+                        if (whole) {
+#pragma unroll
+                            for (int k4 = 0; k4 < NL; k4 += 4) {
+                                const float4 v = *reinterpret_cast<const float4*>(in + t * ldin + ob + k4);
+                                gv[t][k4] = v.x; gv[t][k4 + 1] = v.y; gv[t][k4 + 2] = v.z; gv[t][k4 + 3] = v.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NL; ++k) gv[t][k] = ob + k < o1 ? in[t * ldin + ob + k] : 0.f;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < NL; ++k) {
-                    if (ob + k < o1) {
 #pragma unroll
-                        for (int t = 0; t < MAXT; ++t)
-                            if (t < T) {
-                                const float g = in[t * ldin + ob + k];
-                                acc[t][0] += g * w[k].x; acc[t][1] += g * w[k].y;
-                                acc[t][2] += g * w[k].z; acc[t][3] += g * w[k].w;
-                            }
-                    }
+                    for (int t = 0; t < MAXT; ++t)
+                        if (t < T) {
+                            const float g = gv[t][k];
+                            acc[t][0] += g * w[k].x; acc[t][1] += g * w[k].y;
+                            acc[t][2] += g * w[k].z; acc[t][3] += g * w[k].w;
+                        }
                 }
             }
         }
