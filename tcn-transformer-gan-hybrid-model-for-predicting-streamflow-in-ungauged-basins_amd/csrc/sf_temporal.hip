@@ -47,6 +47,45 @@ __device__ __forceinline__ void dot_row_tokens(const float* __restrict__ wrow, c
     }
 }
 
+// As dot_row_tokens, with the row shared by RP = 8 consecutive lanes: lane q takes the 16-byte
+// chunks q, q + 8, ... of the row, so the eight lanes read 128 contiguous bytes per load (a row
+// per lane touches 64 cache lines per wave instruction), and the partial sums are folded with
+// lane shuffles.  Every lane of the group ends with the full sums.
+constexpr int RP = 8;
+__device__ __forceinline__ void dot_row_tokens_shared(const float* __restrict__ wrow, const float* __restrict__ v,
+                                                      int ldv, int n, int T, int q, float* acc) {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = 0.f;
+    constexpr int NL = 8;
+    const int nchunks = n >> 2;
+    for (int c0 = q; c0 < nchunks; c0 += RP * NL) {
+        float4 w[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int c = c0 + k * RP;
+            w[k] = *reinterpret_cast<const float4*>(wrow + 4 * (c < nchunks ? c : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int c = c0 + k * RP;
+            if (c < nchunks) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+                    if (t < T) {
+                        const float4 vv = *reinterpret_cast<const float4*>(v + t * ldv + 4 * c);
+                        acc[t] += w[k].x * vv.x + w[k].y * vv.y + w[k].z * vv.z + w[k].w * vv.w;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+        if (t < T) {
+#pragma unroll
+            for (int o = RP / 2; o > 0; o >>= 1) acc[t] += __shfl_xor(acc[t], o, 64);
+        }
+}
+
 __device__ __forceinline__ float dot_row(const float* __restrict__ wrow, const float* __restrict__ v, int n) {
     float a = 0.f;
     for (int d = 0; d < n; d += 4) {
@@ -132,7 +171,9 @@ __global__ __launch_bounds__(NT_FWD) void transformer_fwd_kernel(const float* __
 
     for (int i = tid; i < T * D; i += NT) xs[i] = x[(size_t)b * T * D + i];
     __syncthreads();
-    // packed q,k,v projection
+    // the projections with as many rows as threads take a row per thread; the two with 128 rows
+    // share each row among RP lanes
+    const int rq = tid % RP;
     for (int o = tid; o < 3 * D; o += NT) {
         const float bb = bin[o];
         float dacc[MAXT];
@@ -174,11 +215,11 @@ __global__ __launch_bounds__(NT_FWD) void transformer_fwd_kernel(const float* __
         if (sv) s_ctx[i] = a;
     }
     __syncthreads();
-    for (int o = tid; o < D; o += NT) {
+    for (int o = tid / RP; o < D; o += NT / RP) {
         const float bb = bo[o];
         float dacc[MAXT];
-        dot_row_tokens(Wo + (size_t)o * D, ctx, D, D, T, dacc);
-        for (int t = 0; t < T; ++t) {
+        dot_row_tokens_shared(Wo + (size_t)o * D, ctx, D, D, T, rq, dacc);
+        if (rq == 0) for (int t = 0; t < T; ++t) {
             const float v = dacc[t] + bb;
             tmp[t * D + o] = xs[t * D + o] + v * drop_mask(p, seed, b, 1, t * D + o);
         }
@@ -199,11 +240,11 @@ __global__ __launch_bounds__(NT_FWD) void transformer_fwd_kernel(const float* __
         }
     }
     __syncthreads();
-    for (int o = tid; o < D; o += NT) {
+    for (int o = tid / RP; o < D; o += NT / RP) {
         const float bb = b2[o];
         float dacc[MAXT];
-        dot_row_tokens(W2 + (size_t)o * F, hd, F, F, T, dacc);
-        for (int t = 0; t < T; ++t) {
+        dot_row_tokens_shared(W2 + (size_t)o * F, hd, F, F, T, rq, dacc);
+        if (rq == 0) for (int t = 0; t < T; ++t) {
             const float v = dacc[t] + bb;
             tmp[t * D + o] = x1[t * D + o] + v * drop_mask(p, seed, b, 3, t * D + o);
         }
@@ -804,3 +845,4 @@ extern "C" int sf_token_outer4(const float* const* g, const float* const* a, flo
     SF_LAUNCH_CHECK("sf_token_outer4");
     return SF_OK;
 }
+
