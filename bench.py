@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "tcn-transformer-gan-hybrid-model-for-predicting-streamflow-in-ungauged-basins_amd"
 
+PMC_SUMMARY = "r1z_pmc_hbm_traffic.json"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (spec)
 
 
@@ -60,6 +61,20 @@ def cpu_baseline(cfg, batches, steps=2, batch=2):
     dt = time.perf_counter() - t0
     return {"value": round(batch * steps / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{steps} timed steps (after 1 warm-up) of batch {batch}, same config and synthetic inputs, f32"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed counter passes over this same command
+    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, summarised by
+    tools/pmc_summary.py with the gfx950 doubling of FETCH_SIZE for wide reads).  Counters cannot
+    be collected from inside the process, so the figure is the profiled one, not this run's."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_SUMMARY)
+    try:
+        with open(path) as f:
+            row = json.load(f)["kernels"][kernel]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    return row["traffic_bytes_per_launch"], "profiles/" + PMC_SUMMARY
 
 
 def main():
@@ -139,6 +154,7 @@ def main():
     loss = float(ld["total"].detach())
     bad = trainer.saw_nan_or_inf()
     dom_stats = ops.timed_tflops(dom)
+    dom_bytes = ops.timed_bytes(dom)
     del ops.TIMED[dom]
     for t in other_tags:
         ops.TIMED[t] = []
@@ -187,6 +203,7 @@ def main():
         # shapes of the persistent forward / data-gradient kernel (res: weights resident in LDS), wgrad3_dma_kernel the weight gradient (its
         # event pair also spans the small slab-reduction launch that follows it).
         n_l, ms_l, achieved = dom_stats
+        traffic, traffic_src = pmc_traffic(dom)
         others = {}
         for t in other_tags:
             n_o, ms_o, tf_o = other_stats[t]
@@ -203,8 +220,9 @@ def main():
                                    "T=5, Transformer, hidden 128, 64 stations k=5", "batch_per_gpu": a.batch,
                        "global_batch": a.batch * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": dom, "launches": n_l, "ms_per_launch": round(ms_l, 4), "other": others},
+                         "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(dom_bytes), "kernel": dom, "launches": n_l, "ms_per_launch": round(ms_l, 4), "other": others},
             "final_loss": round(loss, 6), "nan_or_inf": bad,
         }
         if with_loader is not None:

@@ -150,6 +150,13 @@ def timed_ms(tag: str):
     return len(ev), sum(r[0].elapsed_time(r[1]) for r in ev) / len(ev)
 
 
+def timed_bytes(tag: str):
+    """Mean algorithmic HBM bytes per launch of a timed tag (input + output + packed weights, each
+    touched once), 0.0 when the tag's records carry no byte count."""
+    ev = [r for r in TIMED.get(tag, []) if len(r) > 3]
+    return sum(r[3] for r in ev) / len(ev) if ev else 0.0
+
+
 def timed_tflops(tag: str):
     """(number of launches, mean ms per launch, TFLOP/s = recorded flops / recorded time)."""
     ev = TIMED.get(tag, [])
@@ -250,7 +257,8 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
         if rec is not None:
             e1.record()
             # algorithmic flops: real (unpadded) channel counts when the caller states them
-            rec.append((e0, e1, 2.0 * N * H * W * (flop_c or C) * (flop_k or K) * 9))
+            rec.append((e0, e1, 2.0 * N * H * W * (flop_c or C) * (flop_k or K) * 9,
+                        x.numel() * x.element_size() + out.numel() * out.element_size() + wp.numel() * wp.element_size()))
         return
     geom = conv_geom(N, H, W, C, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)))
     conv_fprop(x, wp, out, geom, K, bias=bias, act=act, aux=aux, aux_mode=aux_mode, tag=tag)
