@@ -304,10 +304,10 @@ template <int EPC> struct Chan {
 // One batch of U items for the backward kernels: loads first, then dz (gradient wrt the BN
 // output) and x per pre-BN pixel.  MODE 0 items are 2x2 pooling windows (4 pixels each, the
 // window grid covers odd trailing rows / columns too), MODE 1 / 2 items are pixels.
-template <typename T, int MODE> struct BwdBatch {
+template <typename T, int MODE, int UU = 0> struct BwdBatch {
     static constexpr int EPC = Chunk<T>::EPC;
-    static constexpr int U = MODE == 0 ? 2 : 4;
-    static constexpr int PIX = MODE == 0 ? 4 : 1;
+    static constexpr int U = UU ? UU : (MODE == 0 || MODE == 4) ? 2 : 4;
+    static constexpr int PIX = (MODE == 0 || MODE == 4) ? 4 : 1;
     float xf[U][PIX][EPC], dz[U][PIX][EPC];
     unsigned opix[U][PIX];  // pre-BN pixel index (row of x / dx), ~0u when invalid
 
@@ -315,7 +315,70 @@ template <typename T, int MODE> struct BwdBatch {
                                         const PoolTables* tabs) {
         const T* xb = reinterpret_cast<const T*>(a.x) + m.cg * EPC;
         const T* gb = reinterpret_cast<const T*>(a.dy) + m.cg * EPC;
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 4) {
+            // avgpool backward over groups of four consecutive pixels of one image row: the
+            // group lies in one or two row bins and (checked by the launcher) in at most three
+            // consecutive column bins, so 2 x 3 pooled-gradient chunks serve all four pixels.
+            const unsigned GW = (a.W + 3) / 4;
+            uint4 rx[U][4], rg[U][2][3];
+            float wh[U][2], wc[U][4][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned rr = r + u * m.rpp;
+                const bool ok = rr < r1;
+                const unsigned rc = ok ? rr : r;
+                const unsigned t = rc / GW, gw = rc - t * GW;
+                const unsigned n = t / (unsigned)a.H, hh = t - n * a.H;
+                const int hbin = tabs->hb[hh];
+                const int i0 = hbin & 0xffff, i1 = hbin >> 16;
+                wh[u][0] = tabs->ih[i0];
+                wh[u][1] = i1 > i0 ? tabs->ih[i1] : 0.f;
+                const int jlo = tabs->wb[4 * gw] & 0xffff;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned w = 4 * gw + k;
+                    const bool v = ok && w < (unsigned)a.W;
+                    const unsigned pix = (n * a.H + hh) * a.W + w;
+                    opix[u][k] = v ? pix : ~0u;
+                    rx[u][k] = ld16(v ? (const void*)(xb + (size_t)pix * a.C) : zsrc());
+                    const int wbin = tabs->wb[v ? w : 4 * gw];
+                    const int j0 = wbin & 0xffff, j1 = wbin >> 16;
+                    const float f0 = tabs->iw[j0], f1 = j1 > j0 ? tabs->iw[j1] : 0.f;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        wc[u][k][b] = (jlo + b == j0 ? f0 : 0.f) + (jlo + b == j1 ? f1 : 0.f);
+                }
+                const T* gn = gb + (size_t)n * a.OH * a.OW * a.C;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int j = jlo + b < a.OW ? jlo + b : a.OW - 1;   // weight is zero past the last bin
+                    rg[u][0][b] = ld16(gn + (size_t)(i0 * a.OW + j) * a.C);
+                    rg[u][1][b] = ld16(gn + (size_t)(i1 * a.OW + j) * a.C);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float G[3][EPC];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float g0[EPC], g1[EPC];
+                    Chunk<T>::decode(rg[u][0][b], g0);
+                    Chunk<T>::decode(rg[u][1][b], g1);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) G[b][e] = g0[e] * wh[u][0] + g1[e] * wh[u][1];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    Chunk<T>::decode(rx[u][k], xf[u][k]);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float acc = G[0][e] * wc[u][k][0] + G[1][e] * wc[u][k][1] + G[2][e] * wc[u][k][2];
+                        const float y = xf[u][k][e] * ch.sc[e] + ch.sf[e];
+                        dz[u][k][e] = y > 0.f ? acc : 0.f;
+                    }
+                }
+            }
+        } else if constexpr (MODE == 2) {
             uint4 rx[U], rg[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -461,12 +524,13 @@ template <typename T, int MODE> struct BwdBatch {
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(BnBwd a, double* __restrict__ ws) {
-    using Batch = BwdBatch<T, MODE>;
+    // mode 4: one group per batch (two would spill next to the 2 * EPC f64 sums)
+    using Batch = BwdBatch<T, MODE, MODE == 4 ? 1 : 0>;
     constexpr int EPC = Batch::EPC, U = Batch::U, PIX = Batch::PIX;
     const RowMap m(a.C, EPC);
     __shared__ double sm[BT];
     PoolTables* tabs = nullptr;
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 1 || MODE == 4) {
         __shared__ PoolTables tabs_s;
         tabs = &tabs_s;
         build_axis(tabs->hb, tabs->ih, a.H, a.OH);
@@ -519,7 +583,7 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply_kernel(BnBwd a, const double*
     constexpr int EPC = Batch::EPC, U = Batch::U, PIX = Batch::PIX;
     const RowMap m(a.C, EPC);
     PoolTables* tabs = nullptr;
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 1 || MODE == 4) {
         __shared__ PoolTables tabs_s;
         tabs = &tabs_s;
         build_axis(tabs->hb, tabs->ih, a.H, a.OH);
@@ -674,7 +738,27 @@ extern "C" int sf_bn_relu_fwd(const void* x, int dtype, const float* scale, cons
     return bn_act_fwd("sf_bn_relu_fwd", x, dtype, scale, shift, y, M, C, 0.f, stream);
 }
 
-static int fill_bnbwd(BnBwd& a, int mode, const void* x, const void* dy, const float* scale, const float* shift,
+// Largest number of consecutive column bins an aligned group of four pixels touches (in >= out:
+// a pixel lies in one or two bins).
+static int max_group_bins(int in, int out) {
+    int lo[MAX_AXIS], hi[MAX_AXIS];
+    for (int p = 0; p < in; ++p) { lo[p] = out; hi[p] = -1; }
+    for (int i = 0; i < out; ++i) {
+        const int b = (i * in) / out, e = ((i + 1) * in + out - 1) / out;
+        for (int p = b; p < e && p < in; ++p) { if (i < lo[p]) lo[p] = i; if (i > hi[p]) hi[p] = i; }
+    }
+    int worst = 0;
+    for (int g = 0; 4 * g < in; ++g) {
+        const int last = 4 * g + 3 < in ? 4 * g + 3 : in - 1;
+        const int span = hi[last] - lo[4 * g] + 1;
+        if (span > worst) worst = span;
+    }
+    return worst;
+}
+
+// Fills the kernel arguments; returns the grid (negative: error) and in *kmode the kernel variant:
+// the mode itself, or 4 = avgpool backward by groups of four pixels.
+static int fill_bnbwd(BnBwd& a, int mode, int* kmode, const void* x, const void* dy, const float* scale, const float* shift,
                       const float* mean, const float* invstd, const float* gamma, int N, int H, int W, int C,
                       int Creal, int OH, int OW, int training, int dtype, int dy_dtype, int cap) {
     SF_REQUIRE(mode >= 0 && mode <= 3, "bn_bwd: bad mode %d", mode);
@@ -692,8 +776,12 @@ static int fill_bnbwd(BnBwd& a, int mode, const void* x, const void* dy, const f
     a.N = N; a.H = H; a.W = W; a.C = C; a.Creal = Creal; a.OH = OH; a.OW = OW; a.training = training;
     a.slope = mode == 3 ? 0.f : 0.2f;
     const int epc = dtype == SF_BF16 ? 8 : 4;
-    const long long items = mode == 0 ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
-    const Split sp = split_rows(items, (BT / (C / epc)) * (mode == 0 ? 2 : 4), cap, cap <= 512 ? 32 : 1);
+    *kmode = mode == 3 ? 2 : mode;   // modes 2 and 3 differ in a.slope only
+    if (mode == 1 && H >= OH && W >= OW && W >= 8 && max_group_bins(W, OW) <= 3) *kmode = 4;
+    const long long items = mode == 0    ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2)
+                            : *kmode == 4 ? (long long)N * H * ((W + 3) / 4)
+                                          : (long long)N * H * W;
+    const Split sp = split_rows(items, (BT / (C / epc)) * ((mode == 0 || *kmode == 4) ? 2 : 4), cap, cap <= 512 ? 32 : 1);
     a.items = (unsigned)items;
     a.per = sp.per;
     return sp.grid;
@@ -703,13 +791,14 @@ extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* 
                                 const float* shift, const float* mean, const float* invstd, double* ws, int N, int H,
                                 int W, int C, int Creal, int OH, int OW, void* stream) {
     BnBwd a;
-    const int grid = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, scale, N, H, W, C, Creal, OH, OW, 1, dtype,
+    int kmode = 0;
+    const int grid = fill_bnbwd(a, mode, &kmode, x, dy, scale, shift, mean, invstd, scale, N, H, W, C, Creal, OH, OW, 1, dtype,
                                 dy_dtype, SF_BN_WS_PARTS);
     if (grid < 0) return grid;
     SF_REQUIRE(ws, "sf_bn_bwd_reduce: null workspace");
     hipStream_t s = (hipStream_t)stream;
 #define RED(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), dim3(grid), dim3(BT), 0, s, a, ws))
-    if (mode == 0) { RED(0); } else if (mode == 1) { RED(1); } else { RED(2); }   // modes 2 and 3 differ in a.slope only
+    if (kmode == 0) { RED(0); } else if (kmode == 1) { RED(1); } else if (kmode == 4) { RED(4); } else { RED(2); }
 #undef RED
     hipLaunchKernelGGL(ws_fold_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, 2 * C, grid);
     SF_LAUNCH_CHECK("sf_bn_bwd_reduce");
@@ -721,13 +810,14 @@ extern "C" int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* d
                                const double* ws, int training, void* dx, float* dgamma, float* dbeta, int N, int H,
                                int W, int C, int Creal, int OH, int OW, void* stream) {
     BnBwd a;
-    const int grid = fill_bnbwd(a, mode, x, dy, scale, shift, mean, invstd, gamma ? gamma : scale, N, H, W, C, Creal, OH,
+    int kmode = 0;
+    const int grid = fill_bnbwd(a, mode, &kmode, x, dy, scale, shift, mean, invstd, gamma ? gamma : scale, N, H, W, C, Creal, OH,
                                 OW, training, dtype, dy_dtype, 4096);
     if (grid < 0) return grid;
     SF_REQUIRE(ws && dx, "sf_bn_bwd_apply: null argument");
     hipStream_t s = (hipStream_t)stream;
 #define APP(MODE) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MODE>), dim3(grid), dim3(BT), 0, s, a, ws, (T*)dx, dgamma, dbeta))
-    if (mode == 0) { APP(0); } else if (mode == 1) { APP(1); } else { APP(2); }
+    if (kmode == 0) { APP(0); } else if (kmode == 1) { APP(1); } else if (kmode == 4) { APP(4); } else { APP(2); }
 #undef APP
     SF_LAUNCH_CHECK("sf_bn_bwd_apply");
     return SF_OK;

@@ -714,6 +714,34 @@ def test_trainer_validate(sf):
         assert abs(res[k] - want[k]) <= 1e-4 * max(1.0, abs(want[k])), k
 
 
+def test_bn_avgpool_backward_shapes(sf):
+    """sf_bn_bwd_reduce / sf_bn_bwd_apply in adaptive-average-pool mode (train-mode BatchNorm ->
+    ReLU -> adaptive_avg_pool2d, src/model/cnn_encoder.py:60-97) against torch autograd in f32:
+    overlapping bins served by groups of four pixels (100 -> 32, widths that are no multiple of
+    four), exact 2 x 2 bins, and ratios below two where a group spans more than three bins and the
+    per-pixel variant runs.  dx to 1e-4 of its max, dgamma / dbeta to 1e-4."""
+    ops = sf.ops
+    torch.manual_seed(11)
+    for (N, H, W, C, OH, OW) in [(3, 100, 100, 32, 32, 32), (2, 90, 110, 16, 32, 32), (2, 45, 67, 8, 32, 32),
+                                 (2, 40, 36, 8, 32, 32), (2, 64, 64, 8, 32, 32), (1, 33, 131, 8, 32, 32)]:
+        x = torch.randn(N, H, W, C, device=DEV)
+        gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+        dy = torch.randn(N, OH, OW, C, device=DEV)
+        M = N * H * W
+        ws = ops.bn_ws(C, DEV)
+        ops.bn_stats(x, M, C, ws)
+        st = ops.bn_finalize(ws[:2 * C], M, C, C, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True)
+        dx, dgamma, dbeta = ops.bn_backward(1, x, dy, st, gamma, C, True, OH, OW)
+        xr = x.cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        gr, br = gamma.cpu().requires_grad_(True), beta.cpu().requires_grad_(True)
+        y = torch.nn.functional.adaptive_avg_pool2d(
+            torch.relu(torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)), (OH, OW))
+        (y * dy.cpu().permute(0, 3, 1, 2)).sum().backward()
+        close(dx.permute(0, 3, 1, 2), xr.grad.numpy(), 1e-4)
+        close(dgamma, gr.grad.numpy(), 1e-4)
+        close(dbeta, br.grad.numpy(), 1e-4)
+
+
 def test_colsum_f32_shapes(sf):
     """Bias-gradient column sums of the two Linear layers (short and very wide, tall and narrow),
     odd sizes and a single element, against a float64 sum."""
