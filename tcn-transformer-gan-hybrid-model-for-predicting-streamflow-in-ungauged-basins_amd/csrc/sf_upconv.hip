@@ -158,7 +158,9 @@ template <int NV> struct AdjointCursor {  // sums kept as 4-wide vectors (NV / 4
 
 // horizontal pass: tm[row][tx][j][k] = sum_ox lambda_x(ox + tx - 1 -> j) dz[row][ox][k].  A thread
 // owns one gradient row and 8 channels, reads every chunk once (batches of U loads) and feeds
-// the three column shifts.
+// the three column shifts.  The pass is bound by instruction issue (about 200 per output column:
+// three axis evaluations, six cursor updates with their data-dependent branches), not by load
+// latency: splitting a row over four threads with margins ran twice as long.
 template <typename T>
 __global__ __launch_bounds__(UT) void upconv3_bwd_x_kernel(const T* __restrict__ dz, float* __restrict__ tm,
                                                            unsigned rows, int w, int OW, int K) {
@@ -172,28 +174,42 @@ __global__ __launch_bounds__(UT) void upconv3_bwd_x_kernel(const T* __restrict__
     // six 4-channel cursors (3 column shifts x 2 halves): arrays of sums end up in scratch
     AdjointCursor<4> c0a, c0b, c1a, c1b, c2a, c2b;
     c0a.init(); c0b.init(); c1a.init(); c1b.init(); c2a.init(); c2b.init();
-    auto feed = [&](AdjointCursor<4>& c, int tx, int half, int ox, const f32x4& fv) __attribute__((always_inline)) {
-        const int qx = ox + tx - 1;
-        if (qx < 0 || qx >= OW) return;
+    // the column shifts tx = 0, 1, 2 of output column ox use the axis weights of ox - 1, ox, ox + 1:
+    // one evaluation per column, kept in a sliding window
+    AxisW ax_prev = axis_w(0, w, OW), ax_cur = ax_prev;
+    auto feed = [&](AdjointCursor<4>& c, int tx, int half, const AxisW& ax, const f32x4& fv) __attribute__((always_inline)) {
         float* dst = trow + (size_t)tx * w * K + half * 4;
-        c.add(axis_w(qx, w, OW), &fv, [&](int col, const f32x4* v) __attribute__((always_inline)) {
+        c.add(ax, &fv, [&](int col, const f32x4* v) __attribute__((always_inline)) {
             if (col >= 0) *reinterpret_cast<f32x4*>(dst + (size_t)col * K) = v[0];
         });
     };
-    for (int ox0 = 0; ox0 < OW; ox0 += U) {
-        float f[U][8];
+    // two batches of U loads in flight: the next batch is issued before the current one is fed
+    float f[2][U][8];
+    auto fetch = [&](int ox0, float (*dst)[8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) load8<T>(row + (size_t)(ox0 + u < OW ? ox0 + u : OW - 1) * K, f[u]);
+        for (int u = 0; u < U; ++u) load8<T>(row + (size_t)(ox0 + u < OW ? ox0 + u : OW - 1) * K, dst[u]);
+    };
+    auto consume = [&](int ox0, const float (*src)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ox = ox0 + u;
             if (ox < OW) {
-                const f32x4 fa = {f[u][0], f[u][1], f[u][2], f[u][3]}, fb = {f[u][4], f[u][5], f[u][6], f[u][7]};
-                feed(c0a, 0, 0, ox, fa); feed(c0b, 0, 1, ox, fb);
-                feed(c1a, 1, 0, ox, fa); feed(c1b, 1, 1, ox, fb);
-                feed(c2a, 2, 0, ox, fa); feed(c2b, 2, 1, ox, fb);
+                const f32x4 fa = {src[u][0], src[u][1], src[u][2], src[u][3]}, fb = {src[u][4], src[u][5], src[u][6], src[u][7]};
+                const AxisW ax_next = axis_w(ox + 1 < OW ? ox + 1 : OW - 1, w, OW);
+                if (ox > 0) { feed(c0a, 0, 0, ax_prev, fa); feed(c0b, 0, 1, ax_prev, fb); }
+                feed(c1a, 1, 0, ax_cur, fa); feed(c1b, 1, 1, ax_cur, fb);
+                if (ox + 1 < OW) { feed(c2a, 2, 0, ax_next, fa); feed(c2b, 2, 1, ax_next, fb); }
+                ax_prev = ax_cur;
+                ax_cur = ax_next;
             }
         }
+    };
+    fetch(0, f[0]);
+    for (int ox0 = 0; ox0 < OW; ox0 += 2 * U) {
+        fetch(ox0 + U < OW ? ox0 + U : 0, f[1]);
+        consume(ox0, f[0]);
+        fetch(ox0 + 2 * U < OW ? ox0 + 2 * U : 0, f[0]);
+        consume(ox0 + U, f[1]);
     }
     auto done = [&](AdjointCursor<4>& c, int tx, int half) __attribute__((always_inline)) {
         float* dst = trow + (size_t)tx * w * K + half * 4;
