@@ -25,6 +25,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void sf_set_error(const char* fmt, ...);
 
+// Function attributes (dynamic LDS limit) are per device: a call site keeps one of these in a
+// function-local static and sets the attribute the first time it runs on each device.
+struct DeviceOnce {
+    unsigned long long seen[4] = {0, 0, 0, 0};   // devices 0..255
+    int dev = 0;
+    bool done() {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        dev &= 255;
+        return (seen[dev >> 6] >> (dev & 63)) & 1ull;
+    }
+    void mark() { seen[dev >> 6] |= 1ull << (dev & 63); }
+};
+
 #define SF_REQUIRE(cond, ...)                                   \
     do {                                                        \
         if (!(cond)) {                                          \

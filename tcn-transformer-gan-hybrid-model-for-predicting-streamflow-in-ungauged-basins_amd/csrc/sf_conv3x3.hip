@@ -658,14 +658,14 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
     p.nchunks = (p.C + CK - 1) / CK;
     const size_t lds = 2 * (size_t)Cf::BUF + sizeof(float) * D_BIAS_MAX;
     void (*kern)(C3DParams) = RES ? &conv3_dma_res_kernel : KT == 64 ? &conv3_dma_kernel : &conv3_dma_wide_kernel;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("sf_conv3x3: cannot raise the dynamic LDS limit to %zu bytes", lds);
             return SF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     long long items = ntiles * p.ktiles;
     long long grid = (items + 7) / 8 * 8;
@@ -693,14 +693,14 @@ void pick_tile(int H, int W, int* th, int* tw) {
 template <int KT, int CK> int launch3(const C3Params& p, hipStream_t s) {
     constexpr int LD = CK + 8;
     const size_t lds = sizeof(bf16) * ((size_t)9 * KT * LD + (size_t)MAX_PP * LD);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<KT, CK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("sf_conv3x3: cannot raise the dynamic LDS limit to %zu bytes", lds);
             return SF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     const long long nblk = (long long)p.N * p.tiles_y * p.tiles_x * p.ktiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) { sf_set_error("sf_conv3x3: bad grid"); return SF_EINVAL; }

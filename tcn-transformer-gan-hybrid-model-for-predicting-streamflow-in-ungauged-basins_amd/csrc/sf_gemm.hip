@@ -425,14 +425,14 @@ int launch_one(const KParams& q, hipStream_t s) {
     constexpr int LDB = B_KM ? (TJ + M::PAD_KM) : (BK + M::PAD_RM);
     constexpr size_t lds = sizeof(T) * 2 * ((A_KM ? BK * LDA : TI * LDA) + (B_KM ? BK * LDB : TJ * LDB));
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DeviceOnce attr_set;
+        if (!attr_set.done()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, A_KM, B_KM, TI, BK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 sf_set_error("sf_gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
                 return SF_ELAUNCH;
             }
-            attr_set = true;
+            attr_set.mark();
         }
     }
     KParams p = q;

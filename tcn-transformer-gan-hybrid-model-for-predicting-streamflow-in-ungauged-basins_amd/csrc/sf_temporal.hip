@@ -751,14 +751,14 @@ extern "C" int sf_transformer_layer_bwd(const float* x, const float* dy, float* 
     const int j4 = D / 4, parts = j4 >= NT ? 1 : NT / j4;
     const size_t lds = sizeof(float) * ((size_t)T * (2 * D + F + 3 * D) + 8 * T * T + (size_t)parts * MAXT * D);
     SF_REQUIRE(lds <= 160 * 1024 && D % 4 == 0 && F % 4 == 0, "sf_transformer_layer_bwd: sequence does not fit in LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&transformer_bwd_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             sf_set_error("sf_transformer_layer_bwd: cannot raise the dynamic LDS limit");
             return SF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(transformer_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, x, dy, dx, W, G, save, gtok,
                        T, D, F, nhead, p_drop, seed);

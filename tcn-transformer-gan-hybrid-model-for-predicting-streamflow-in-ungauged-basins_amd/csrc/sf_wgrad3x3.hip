@@ -470,14 +470,14 @@ int run_wgrad(const void* x, const void* dout, float* dw, float* ws, size_t ws_b
     p.nslices = nslices;
     p.tiles_per_slice = (p.ntiles + nslices - 1) / nslices;
     const size_t lds = (size_t)Cf::TPMAX * SA + (size_t)Cf::PPMAX * Cf::SB;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_patch_kernel<TAPS, STRIDE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", who, lds);
             return SF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL((wgrad_patch_kernel<TAPS, STRIDE>), dim3((unsigned)(nslices * p.kt_tiles * p.ct_tiles)),
                        dim3(NTW), lds, s, p);
@@ -532,14 +532,14 @@ int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t
     p.nslices = nslices;
     p.tiles_per_slice = 0;
     const size_t lds = 2 * (size_t)G_BUF;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_dma_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", who, lds);
             return SF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(wgrad3_dma_kernel, dim3((unsigned)(nslices * p.kt_tiles * p.ct_tiles)), dim3(NTW), lds, s, p);
     const long long total = (long long)K * 9 * Cin;
