@@ -146,9 +146,29 @@ class Trainer:
         self._pending: List = []
         self._reduce_now = False
         if self.distributed:
+            self._broadcast_initial_state()
             self._install_early_reduce()
 
     # ---- data parallel ------------------------------------------------------------------
+    def _broadcast_initial_state(self):
+        """Every rank starts from rank 0's parameters and buffers (what DistributedDataParallel
+        does at construction), so ranks that were seeded differently or loaded different files
+        still hold one model."""
+        nets = [self.model] + ([self.discriminator] if self.use_gan else [])
+        by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+        for net in nets:
+            for t in list(net.parameters()) + list(net.buffers()):
+                by_dtype.setdefault(t.dtype, []).append(t.data)
+        with torch.no_grad():
+            for group in by_dtype.values():     # one collective per dtype, not one per tensor
+                flat = torch.cat([t.reshape(-1) for t in group])
+                torch.cuda.synchronize(self.device)
+                dist.broadcast(flat, 0)
+                torch.cuda.synchronize(self.device)
+                off = 0
+                for t in group:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
     def _install_early_reduce(self):
         """The two 262144-wide Linear weights are 95 % of the gradient bytes; their gradients are
         complete long before the encoder's backward finishes, so each is all-reduced in place

@@ -32,6 +32,8 @@ def _run(sf, distributed, batches):
     training = importlib.import_module(sf.__name__ + ".training")
     tr = training.Trainer(_cfg(), device="cuda", distributed=distributed)
     assert len(tr.opt_g.big) >= 1 and len(tr.opt_g.small) >= 10
+    # state right after construction: with ranks seeded differently it must already be rank 0's
+    init = (tr.opt_g.flat.cpu().clone(), tr.opt_g.big[0].detach().cpu().clone(), tr.opt_d.flat.cpu().clone())
     load_gold(tr.model, "trn_g_trgan")
     load_gold(tr.discriminator, "trn_d_trgan")
     tr.model.temporal_module.dropout = 0.0
@@ -41,7 +43,7 @@ def _run(sf, distributed, batches):
         losses.append(float(o["total"].detach()))
     torch.cuda.synchronize()
     assert not tr.saw_nan_or_inf()
-    return tr.opt_g.flat.cpu(), tr.opt_d.flat.cpu(), losses
+    return tr.opt_g.flat.cpu(), tr.opt_d.flat.cpu(), losses, init
 
 
 def _worker(rank, world, port, same_data, out):
@@ -62,6 +64,7 @@ def _worker(rank, world, port, same_data, out):
     dist.all_reduce = synced_all_reduce
     try:
         sf = load_pkg()
+        torch.manual_seed(1234 + rank)       # different random initialisation per rank
         batches = make_batches(2 * STEPS, 2, 3, 64)
         mine = batches[:STEPS] if (same_data or rank == 0) else batches[STEPS:]
         out[rank] = _run(sf, True, mine)
@@ -84,7 +87,8 @@ def test_two_ranks_stay_in_lockstep_on_different_data():
     on different data both ranks hold bit-identical generator and discriminator parameters."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    (g0, d0, l0), (g1, d1, l1) = _spawn(same_data=False)
+    (g0, d0, l0, i0), (g1, d1, l1, i1) = _spawn(same_data=False)
+    assert all(torch.equal(a, b) for a, b in zip(i0, i1))   # rank 0's initial state was broadcast
     assert torch.equal(g0, g1) and torch.equal(d0, d1)
     assert l0 != l1                      # the ranks did see different batches
     assert np.isfinite(l0 + l1).all()
@@ -95,9 +99,9 @@ def test_two_ranks_on_the_same_data_match_one_process():
     single-process run (same tolerance as the reference-trajectory test: f32 atomics order)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    (g0, d0, l0), (g1, d1, _) = _spawn(same_data=True)
+    (g0, d0, l0, _), (g1, d1, _, _) = _spawn(same_data=True)
     assert torch.equal(g0, g1) and torch.equal(d0, d1)
-    gs, ds, ls = _run(load_pkg(), False, make_batches(2 * STEPS, 2, 3, 64)[:STEPS])
+    gs, ds, ls, _ = _run(load_pkg(), False, make_batches(2 * STEPS, 2, 3, 64)[:STEPS])
     np.testing.assert_allclose(l0, ls, rtol=5e-4)
     close(g0, gs.numpy(), 2e-3)
     close(d0, ds.numpy(), 2e-3)
