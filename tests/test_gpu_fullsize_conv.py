@@ -1,0 +1,90 @@
+"""The persistent 3x3 conv / data-gradient / weight-gradient kernels at the benchmark's two full
+shapes (encoder conv2: 160 frames of 100 x 100, 128 -> 256; decoder conv2: 32 maps of 400 x 400,
+64 -> 64): every workgroup walks many tiles there, which the small parity cases do not exercise.
+Checked against the generic implicit-GEMM kernels on the whole tensors (an independent
+implementation in the same library, itself pinned by the small cases against f32 references) and
+against an f32 torch conv on the first and the last image.  Tolerance 1e-2 of the tensor's max
+(bf16 output rounding; both sides accumulate in f32)."""
+import pytest
+import torch
+
+from conftest import close, load_pkg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SHAPES = [(160, 100, 100, 128, 256), (32, 400, 400, 64, 64)]
+
+
+@pytest.fixture(scope="module")
+def sf():
+    return load_pkg()
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max())
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_full_size_conv_forward_and_data_gradient(sf, shape):
+    ops = sf.ops
+    N, H, W, C, K = shape
+    torch.manual_seed(9)
+    x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(K, C, 3, 3, device=DEV) / (3.0 * C ** 0.5)).to(torch.bfloat16).float()
+    b = torch.randn(K, device=DEV)
+    wp = ops.pack_conv_weight(w.contiguous(), torch.bfloat16, list(range(9)), False, K, C)
+    out = torch.empty(N, H, W, K, device=DEV, dtype=torch.bfloat16)
+    ops.conv3x3(x, wp, out, K, bias=b, act=ops.ACT_RELU)
+    ref = torch.empty_like(out)
+    ops.FORCE_GENERIC_CONV = True
+    try:
+        ops.conv3x3(x, wp, ref, K, bias=b, act=ops.ACT_RELU)
+    finally:
+        ops.FORCE_GENERIC_CONV = False
+    assert _rel(out, ref) <= 1e-2
+    for n in (0, N - 1):
+        f32 = torch.relu(torch.nn.functional.conv2d(x[n:n + 1].float().permute(0, 3, 1, 2).cpu(), w.cpu(), b.cpu(), padding=1))
+        close(out[n:n + 1].float().permute(0, 3, 1, 2), f32.numpy(), 1e-2)
+    # data gradient with a ReLU mask
+    dz = torch.randn(N, H, W, K, device=DEV).to(torch.bfloat16)
+    mask = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+    wT = ops.pack_conv_weight(w.contiguous(), torch.bfloat16, list(range(9)), True, C, K)
+    dx = torch.empty(N, H, W, C, device=DEV, dtype=torch.bfloat16)
+    ops.conv3x3(dz, wT, dx, C, dgrad=True, aux=mask, aux_mode=1)
+    dref = torch.empty_like(dx)
+    ops.FORCE_GENERIC_CONV = True
+    try:
+        ops.conv3x3(dz, wT, dref, C, dgrad=True, aux=mask, aux_mode=1)
+    finally:
+        ops.FORCE_GENERIC_CONV = False
+    assert _rel(dx, dref) <= 1e-2
+    n = N - 1
+    f32 = torch.nn.grad.conv2d_input((1, C, H, W), w.cpu(), dz[n:n + 1].float().permute(0, 3, 1, 2).cpu(), padding=1)
+    f32 = f32 * (mask[n:n + 1].float().permute(0, 3, 1, 2).cpu() > 0)
+    close(dx[n:n + 1].float().permute(0, 3, 1, 2), f32.numpy(), 1e-2)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_full_size_weight_gradient(sf, shape):
+    """Linearity pins the full-size sum: dW(x, dz) over all images equals the sum of dW over two
+    halves of the batch (f32 accumulation, 1e-4), and one half-sized call equals the generic GEMM."""
+    ops = sf.ops
+    N, H, W, C, K = shape
+    torch.manual_seed(10)
+    x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+    dz = torch.randn(N, H, W, K, device=DEV).to(torch.bfloat16)
+    dw = torch.empty(K, C, 3, 3, device=DEV)
+    ops.wgrad3x3(x, dz, dw)
+    h = N // 2
+    d0, d1 = torch.empty_like(dw), torch.empty_like(dw)
+    ops.wgrad3x3(x[:h].contiguous(), dz[:h].contiguous(), d0)
+    ops.wgrad3x3(x[h:].contiguous(), dz[h:].contiguous(), d1)
+    assert _rel(dw, d0 + d1) <= 1e-4
+    q = max(1, N // 16)
+    dq = torch.empty_like(dw)
+    ops.wgrad3x3(x[:q].contiguous(), dz[:q].contiguous(), dq)
+    dg = torch.zeros_like(dw)
+    taps = [(r - 1, s - 1) for r in range(3) for s in range(3)]
+    geom = ops.conv_geom(q, H, W, C, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)), cin_real=C, RS=9)
+    ops.conv_wgrad(x[:q].contiguous(), dz[:q].contiguous(), dg, geom, K)
+    assert _rel(dq, dg) <= 1e-4
