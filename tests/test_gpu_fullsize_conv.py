@@ -88,3 +88,31 @@ def test_full_size_weight_gradient(sf, shape):
     geom = ops.conv_geom(q, H, W, C, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)), cin_real=C, RS=9)
     ops.conv_wgrad(x[:q].contiguous(), dz[:q].contiguous(), dg, geom, K)
     assert _rel(dq, dg) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_full_size_upconv_batch_independence(sf, dtype):
+    """sf_upconv3_fwd / sf_upconv3_bwd at the decoder's full shape (32 maps, 32 x 32 -> 400 x 400,
+    64 channels): an image's result does not depend on the batch it travels in, so the rows of a
+    32-image call must equal, bit for bit, a 2-image call on the same data (whose values the
+    small-shape test pins against interpolate + conv)."""
+    ops = sf.ops
+    B, h, w, OH, OW, K = 32, 32, 32, 400, 400, 64
+    torch.manual_seed(12)
+    y9 = torch.randn(B, h, w, 9, K, device=DEV)
+    bias = torch.randn(K, device=DEV)
+    out = ops.upconv3_fwd(y9, bias, OH, OW, dtype, relu=True)
+    for sl in (slice(0, 2), slice(B - 2, B)):
+        part = ops.upconv3_fwd(y9[sl].contiguous(), bias, OH, OW, dtype, relu=True)
+        assert torch.equal(out[sl], part)
+    dz = torch.randn(B, OH, OW, K, device=DEV).to(dtype)
+    g = ops.upconv3_bwd(dz, h, w, dtype)
+    for sl in (slice(0, 2), slice(B - 2, B)):
+        part = ops.upconv3_bwd(dz[sl].contiguous(), h, w, dtype)
+        assert torch.equal(g[sl], part)
+    # adjoint identity <up(y9), dz> = <y9, up^T(dz)> (no bias, no ReLU), f32 only
+    if dtype == torch.float32:
+        lin = ops.upconv3_fwd(y9, None, OH, OW, dtype, relu=False)
+        lhs = float((lin.double() * dz.double()).sum())
+        rhs = float((y9.double() * g.view(B, h, w, 9, K).double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)

@@ -619,7 +619,8 @@ def test_enc1_fused_layer_against_separate_kernels(sf):
     ops = sf.ops
     torch.manual_seed(7)
     for (N, H, W, Cin, K, training) in [(2, 32, 32, 10, 128, True), (3, 37, 53, 10, 128, True), (1, 200, 200, 14, 128, True),
-                                        (2, 17, 16, 3, 256, True), (2, 40, 24, 10, 128, False)]:
+                                        (2, 17, 16, 3, 256, True), (2, 40, 24, 10, 128, False),
+                                        (160, 200, 200, 10, 128, True)]:    # the benchmark's full shape
         x = torch.zeros(N, H, W, 16, device=DEV)
         x[..., :Cin] = torch.randn(N, H, W, Cin, device=DEV)
         x = x.to(torch.bfloat16)
