@@ -116,3 +116,37 @@ def test_full_size_upconv_batch_independence(sf, dtype):
         lhs = float((lin.double() * dz.double()).sum())
         rhs = float((y9.double() * g.view(B, h, w, 9, K).double()).sum())
         assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+
+
+@pytest.mark.parametrize("layer", [(200, 64, 128), (100, 128, 256), (50, 256, 512)])
+def test_full_size_patchgan_stride2_layers(sf, layer):
+    """The PatchGAN's 4x4 stride-2 convs (src/model/gan.py:30-52) at the benchmark's batch of 32
+    maps: forward through the implicit GEMM and weight gradient through sf_wgrad4x4s2.  The GEMM
+    flattens the batch into one pixel axis, so the full call must reproduce a two-image call bit
+    for bit on those images; the first image is checked against an f32 conv (1e-2: bf16 output);
+    the weight gradient is additive over halves of the batch (1e-4)."""
+    import importlib
+    ops = sf.ops
+    fn = importlib.import_module(sf.__name__ + ".functional")
+    IH, C, K = layer
+    N, OH = 32, IH // 2
+    torch.manual_seed(13)
+    x = torch.randn(N, IH, IH, C, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(K, C, 4, 4, device=DEV) / (4.0 * C ** 0.5)).to(torch.bfloat16).float()
+    b = torch.randn(K, device=DEV)
+    wp = ops.pack_conv_weight(w.contiguous(), torch.bfloat16, list(range(16)), False, K, C)
+    z = torch.empty(N, OH, OH, K, device=DEV, dtype=torch.bfloat16)
+    ops.conv_fprop(x, wp, z, fn._s2_geom(N, IH, IH, C, OH, OH), K, bias=b)
+    for sl in (slice(0, 2), slice(N - 2, N)):
+        part = torch.empty(2, OH, OH, K, device=DEV, dtype=torch.bfloat16)
+        ops.conv_fprop(x[sl].contiguous(), wp, part, fn._s2_geom(2, IH, IH, C, OH, OH), K, bias=b)
+        assert torch.equal(z[sl], part)
+    f32 = torch.nn.functional.conv2d(x[:1].float().permute(0, 3, 1, 2).cpu(), w.cpu(), b.cpu(), stride=2, padding=1)
+    close(z[:1].float().permute(0, 3, 1, 2), f32.numpy(), 1e-2)
+    dz = torch.randn(N, OH, OH, K, device=DEV).to(torch.bfloat16)
+    dw, d0, d1 = (torch.empty(K, C, 4, 4, device=DEV) for _ in range(3))
+    ops.wgrad4x4s2(x, dz, dw)
+    h = N // 2
+    ops.wgrad4x4s2(x[:h].contiguous(), dz[:h].contiguous(), d0)
+    ops.wgrad4x4s2(x[h:].contiguous(), dz[h:].contiguous(), d1)
+    assert _rel(dw, d0 + d1) <= 1e-4
