@@ -150,3 +150,33 @@ def test_full_size_patchgan_stride2_layers(sf, layer):
     ops.wgrad4x4s2(x[:h].contiguous(), dz[:h].contiguous(), d0)
     ops.wgrad4x4s2(x[h:].contiguous(), dz[h:].contiguous(), d1)
     assert _rel(dw, d0 + d1) <= 1e-4
+
+
+def test_full_size_encoder_batchnorm_pool_passes(sf):
+    """Second encoder layer's BatchNorm -> ReLU -> adaptive pool (100 x 100 -> 32 x 32, 256 channels,
+    160 frames; src/model/cnn_encoder.py:60-97) at full size: the bf16 kernels against the f32
+    kernels of the same entry points on the same (bf16-representable) values -- the f32 ones are
+    pinned against autograd at small shapes.  Statistics 1e-5, pooled output 1e-2, gradients 2e-2 of
+    the max (bf16 rounding of the outputs; the inputs are identical)."""
+    ops = sf.ops
+    N, H, W, C, OH = 160, 100, 100, 256, 32
+    torch.manual_seed(17)
+    xb = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    dyb = torch.randn(N, OH, OH, C, device=DEV).to(torch.bfloat16)
+    res = {}
+    for dt in (torch.bfloat16, torch.float32):
+        x, dy = xb.to(dt), dyb.to(dt)
+        ws = ops.bn_ws(C, DEV)
+        ops.bn_stats(x, N * H * W, C, ws)
+        st = ops.bn_finalize(ws[:2 * C], N * H * W, C, C, gamma, beta, rm.clone(), rv.clone(), True)
+        y = ops.bn_relu_avgpool_fwd(x, st, C, OH, OH, torch.float32)
+        dx, dg, db = ops.bn_backward(1, x, dy, st, gamma, C, True, OH, OH)
+        res[dt] = (st.clone(), y, dx.float(), dg, db)
+        del x, dy, dx
+    a, b = res[torch.bfloat16], res[torch.float32]
+    assert _rel(a[0], b[0]) <= 1e-5
+    assert _rel(a[1], b[1]) <= 1e-2
+    assert _rel(a[2], b[2]) <= 2e-2
+    assert _rel(a[3], b[3]) <= 2e-2 and _rel(a[4], b[4]) <= 2e-2
