@@ -180,3 +180,30 @@ def test_full_size_encoder_batchnorm_pool_passes(sf):
     assert _rel(a[1], b[1]) <= 1e-2
     assert _rel(a[2], b[2]) <= 2e-2
     assert _rel(a[3], b[3]) <= 2e-2 and _rel(a[4], b[4]) <= 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_full_size_output_conv_passes(sf, dtype):
+    """Decoder output conv (ReLU'd 64-channel map -> 1 channel, 1x1; src/model/decoder.py:174-177) at
+    32 x 400 x 400: sf_conv_k1_fwd and the fused backward (input gradient with the ReLU mask, weight,
+    bias and channel-sum gradients in one pass) against torch expressions in f64 on the same
+    operands.  Forward 1e-5 (f32 accumulation); input gradient exact up to its output rounding
+    (1e-2 bf16 / 1e-6 f32); the reduced gradients 1e-4."""
+    ops = sf.ops
+    N, H, W, C = 32, 400, 400, 64
+    torch.manual_seed(18)
+    x = torch.relu(torch.randn(N, H, W, C, device=DEV)).to(dtype)        # post-ReLU activations, half of them zero
+    w = torch.randn(1, C, 1, 1, device=DEV) / C ** 0.5
+    b = torch.randn(1, device=DEV)
+    y = ops.conv_k1_fwd(x, w, b, 1, 0)
+    yr = (x.double() * w.view(C).double()).sum(-1) + b.double()
+    assert _rel(y.view(N, H, W), yr) <= 1e-5
+    dy = torch.randn(N, 1, H, W, device=DEV)
+    assert ops.conv_k1_bwd_fused_ok(x)
+    dx, dw, db, dsum = ops.conv_k1_bwd_fused(x, dy, w, C)
+    dxr = dy.view(N, H, W, 1).double() * w.view(C).double() * (x > 0)
+    assert _rel(dx, dxr) <= (1e-2 if dtype == torch.bfloat16 else 1e-6)
+    assert _rel(dw.view(C), (dy.view(N, H, W, 1).double() * x.double()).sum((0, 1, 2))) <= 1e-4
+    assert _rel(db, dy.double().sum().view(1)) <= 1e-4
+    # the channel sums are those of the input gradient as stored (rounded to the storage dtype)
+    assert _rel(dsum, dx.double().sum((0, 1, 2))) <= 1e-4
