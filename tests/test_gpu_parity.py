@@ -536,7 +536,8 @@ def test_dconv1_kernels_against_f32_conv(sf):
     ops = sf.ops
     torch.manual_seed(5)
     F = torch.nn.functional
-    for (N, H, W) in [(2, 64, 64), (3, 50, 50), (1, 33, 47), (2, 400, 400), (1, 2, 16)]:
+    for (N, H, W) in [(2, 64, 64), (3, 50, 50), (1, 33, 47), (2, 400, 400), (1, 2, 16),
+                      (32, 400, 400)]:               # the benchmark's full shape
         K = 64
         x = torch.randn(N, 1, H, W, device=DEV).to(torch.bfloat16).float()
         w = (torch.randn(K, 1, 4, 4, device=DEV) * 0.25).to(torch.bfloat16).float()
@@ -546,11 +547,11 @@ def test_dconv1_kernels_against_f32_conv(sf):
         close(y.float().permute(0, 3, 1, 2), ref.numpy(), 1e-2)
         OH, OW = y.shape[1], y.shape[2]
         dz = torch.randn(N, OH, OW, K, device=DEV).to(torch.bfloat16)
-        dzc = dz.float().permute(0, 3, 1, 2).cpu()
+        dzc = dz.double().permute(0, 3, 1, 2).cpu()      # f64 references: the sums run over up to 1.3 M pixels
         dx = ops.dconv1_bwd_data(dz, w, H, W)
-        close(dx, torch.nn.grad.conv2d_input((N, 1, H, W), w.cpu(), dzc, stride=2, padding=1).numpy(), 1e-4)
+        close(dx, torch.nn.grad.conv2d_input((N, 1, H, W), w.double().cpu(), dzc, stride=2, padding=1).numpy(), 1e-4)
         dw, db = ops.dconv1_bwd_weight(x, dz)
-        close(dw, torch.nn.grad.conv2d_weight(x.cpu(), (K, 1, 4, 4), dzc, stride=2, padding=1).numpy(), 1e-4)
+        close(dw, torch.nn.grad.conv2d_weight(x.double().cpu(), (K, 1, 4, 4), dzc, stride=2, padding=1).numpy(), 1e-4)
         close(db, dzc.sum(dim=(0, 2, 3)).numpy(), 1e-4)
 
 
