@@ -334,9 +334,11 @@ int sf_colsum_f32(const float* x, long long M, long long C, float* out, void* st
 
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* torch.optim.Adam step (src/train.py:80-91; eps 1e-8, no weight decay), one fused pass over
- * a flat parameter range.  bias corrections are passed in (1-beta^t). */
-int sf_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
-            float beta2, float eps, float bc1, float bc2, float grad_scale, void* stream);
+ * a flat parameter range.  bias corrections are passed in (1-beta^t).  The betas are doubles: the
+ * 1 - beta factors are formed in double and then rounded to f32, as torch does (1 - 0.999 formed
+ * in f32 is off by 5e-5 of its value). */
+int sf_adam(float* p, const float* g, float* m, float* v, long long n, float lr, double beta1,
+            double beta2, float eps, float bc1, float bc2, float grad_scale, void* stream);
 /* flag[0] |= 1 if any element of x is NaN/Inf (src/train.py:193,198,221) */
 int sf_nan_inf_flag(const float* x, long long n, int* flag, void* stream);
 

@@ -311,14 +311,14 @@ __global__ void bce_reduce_kernel(const float* __restrict__ x, long long n, floa
 __global__ void bce_finish_kernel(const double* ws, long long n, float* loss) { loss[0] = (float)(ws[0] / (double)n); }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2, float gs) {
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float omb1, float omb2,
+                            float eps, float bc1, float bc2, float gs) {
     const float step = lr / bc1;
     const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
         const float gi = g[i] * gs;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
         m[i] = mi;
         v[i] = vi;
         p[i] -= step * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
@@ -428,13 +428,13 @@ extern "C" int sf_bce_logits(const float* x, long long n, float label, const flo
     return SF_OK;
 }
 
-extern "C" int sf_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+extern "C" int sf_adam(float* p, const float* g, float* m, float* v, long long n, float lr, double beta1, double beta2,
                        float eps, float bc1, float bc2, float grad_scale, void* stream) {
     SF_REQUIRE(p && g && m && v && n > 0, "sf_adam: bad arguments");
     SF_REQUIRE(bc1 > 0.f && bc2 > 0.f, "sf_adam: bias corrections must be positive");
     int grid = (int)((n + NT - 1) / NT); if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       bc1, bc2, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, lr, (float)beta1,
+                       (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, bc1, bc2, grad_scale);
     SF_LAUNCH_CHECK("sf_adam");
     return SF_OK;
 }

@@ -817,7 +817,7 @@ def bce_logits(x: torch.Tensor, label: float, labels: Optional[torch.Tensor] = N
 def adam(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     _dev(p, g, m, v, dtypes=[torch.float32] * 4)
     bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
-    _check(lib().sf_adam(_p(p), _p(g), _p(m), _p(v), _c_ll(p.numel()), _c_f(lr), _c_f(beta1), _c_f(beta2), _c_f(eps),
+    _check(lib().sf_adam(_p(p), _p(g), _p(m), _p(v), _c_ll(p.numel()), _c_f(lr), ctypes.c_double(beta1), ctypes.c_double(beta2), _c_f(eps),
                          _c_f(bc1), _c_f(bc2), _c_f(grad_scale), _stream()), "sf_adam")
 
 
