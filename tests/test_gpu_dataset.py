@@ -204,7 +204,7 @@ def test_date_image_metrics_kernel_against_scipy(sf):
     import importlib
     E = importlib.import_module(sf.__name__ + ".evaluation")
     rs = np.random.RandomState(4)
-    for (B, H, W) in [(3, 400, 400), (2, 37, 70), (2, 3, 9), (1, 1, 1)]:
+    for (B, H, W) in [(3, 400, 400), (2, 37, 70), (2, 3, 9), (1, 1, 1), (32, 400, 400)]:   # last: a full evaluation batch
         p = rs.standard_normal((B, H, W)).astype(np.float32)
         t = (0.6 * p + 0.4 * rs.standard_normal((B, H, W))).astype(np.float32)
         if B > 1:
