@@ -1,0 +1,67 @@
+"""The whole adversarial train step at the benchmark's model size (10 channels, 200 x 200 ->
+400 x 400, Transformer, hidden 128, PatchGAN width 64, 64 stations with 5 x 5 windows;
+src/train.py:154-305) in f32 mode, two samples per batch, three batches (a discriminator batch and
+two generator-only batches of the reference's schedule): loss trajectory against the CPU oracle's
+TrainerOracle on the same weights and inputs (5e-4, the tolerance of the golden trajectory test),
+and abs-sum checksums of every generator / discriminator tensor after the three fused Adam steps
+(1e-3)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import goldgen as G
+from conftest import load_pkg
+from oracle import streamflow_oracle as O
+from test_gpu_parity import load_gold
+
+pytestmark = pytest.mark.gpu
+CFG = {
+    "data": {"image_size": [200, 200], "window_size": 5, "upscale_factor": 2},
+    "model": {"input_channels": 10, "hidden_dim": 128, "num_layers": 2, "temporal_module": "Transformer",
+              "use_gan": True, "gan_weight": 0.1},
+    "train": {"lr": 1e-4},
+    "loss": {"metric": "MSE", "weights": {"image": 1.0, "station": 0.5}},
+    "stations": {"kernel_size": 5, "metric": "MSE"},
+    "system": {"grad_accum_steps": 1, "mixed_precision": False},
+}
+
+
+def _batches(nb, B=2, S=64):
+    out = []
+    for i in range(nb):
+        rs = np.random.RandomState(500 + i)
+        pos = [torch.from_numpy(rs.randint(0, 200, size=(S, 2)).astype(np.int64)) for _ in range(B)]
+        run = [torch.from_numpy(rs.standard_normal(S).astype(np.float32)) for _ in range(B)]
+        out.append({"images": G.gold_tensor(f"fs/img{i}", (B, 5, 10, 200, 200)),
+                    "output_image": G.gold_tensor(f"fs/out{i}", (B, 1, 200, 200)),
+                    "station_positions": pos, "stations": run})
+    return out
+
+
+def test_full_size_train_steps_against_oracle():
+    sf = load_pkg()
+    training = importlib.import_module(sf.__name__ + ".training")
+    tr = training.Trainer(CFG, device="cuda")
+    g_sd = load_gold(tr.model, "fs_g")
+    d_sd = load_gold(tr.discriminator, "fs_d")
+    tr.model.temporal_module.dropout = 0.0
+    ref = O.TrainerOracle(CFG, {k: v.clone() for k, v in g_sd.items()}, {k: v.clone() for k, v in d_sd.items()})
+    keys = ("total", "image", "station", "gan_g", "gan_d")
+    for b in _batches(3):
+        args = (b["images"], b["output_image"], b["station_positions"], b["stations"])
+        o = tr.train_step(*args)
+        w = ref.step(*args)
+        assert set(k for k in keys if k in o) == set(k for k in keys if k in w)
+        for k in keys:
+            if k in w:
+                assert abs(float(o[k].detach() if torch.is_tensor(o[k]) else o[k]) - w[k]) <= 5e-4 * max(abs(w[k]), 1e-3), (k, o[k], w[k])
+    assert not tr.saw_nan_or_inf()
+    for mod, sd in ((tr.model, ref.g_sd), (tr.discriminator, ref.d_sd)):
+        for k, v in mod.state_dict().items():
+            if not v.dtype.is_floating_point:
+                assert int(v) == int(sd[k]), k
+                continue
+            a, b_ = float(v.double().abs().sum()), float(sd[k].detach().double().abs().sum())
+            assert abs(a - b_) <= 1e-3 * max(b_, 1e-6), (k, a, b_)
