@@ -40,10 +40,17 @@ def _batches(nb, B=2, S=64):
     return out
 
 
-def test_full_size_train_steps_against_oracle():
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_size_train_steps_against_oracle(mode):
+    """bf16 (the benchmark's mode: autocast on, bf16 tensors, f32 accumulation) against the same f32
+    oracle at the stated bf16 tolerance, 3e-2 of each loss value."""
+    import copy
     sf = load_pkg()
     training = importlib.import_module(sf.__name__ + ".training")
-    tr = training.Trainer(CFG, device="cuda")
+    cfg = copy.deepcopy(CFG)
+    cfg["system"]["mixed_precision"] = mode == "bf16"
+    tol = 5e-4 if mode == "f32" else 3e-2
+    tr = training.Trainer(cfg, device="cuda")
     g_sd = load_gold(tr.model, "fs_g")
     d_sd = load_gold(tr.discriminator, "fs_d")
     tr.model.temporal_module.dropout = 0.0
@@ -56,7 +63,7 @@ def test_full_size_train_steps_against_oracle():
         assert set(k for k in keys if k in o) == set(k for k in keys if k in w)
         for k in keys:
             if k in w:
-                assert abs(float(o[k].detach() if torch.is_tensor(o[k]) else o[k]) - w[k]) <= 5e-4 * max(abs(w[k]), 1e-3), (k, o[k], w[k])
+                assert abs(float(o[k].detach() if torch.is_tensor(o[k]) else o[k]) - w[k]) <= tol * max(abs(w[k]), 1e-3), (k, o[k], w[k])
     assert not tr.saw_nan_or_inf()
     for mod, sd in ((tr.model, ref.g_sd), (tr.discriminator, ref.d_sd)):
         for k, v in mod.state_dict().items():
