@@ -324,6 +324,26 @@ int sf_image_station_loss(const float* pred, const float* target, const int* pos
                           float zero_threshold, int ksize, int station_metric, float image_weight,
                           float station_weight, float* losses, float* dpred, double* ws,
                           void* stream);
+/*
+ * The same computation for callers that cannot allocate device memory or pass a workspace (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+ * in the reference.  The partial sums live in a 32 KB file-scope __device__ array of the library
+ * (one copy per GPU, held until the process ends) whose per-device address is taken with
+ * hipGetSymbolAddress on the first call on that device; the call itself allocates and frees
+ * nothing.  Limits (SF_EINVAL beyond them): B*H*W <= SF_LOSS_STATIC_MAX_PIXELS and
+ * S <= SF_LOSS_STATIC_MAX_STATIONS.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (different streams or host threads) race; calls ordered on one stream do not
+ * (every call rewrites all the slots it reads).  Make the first call on a device outside graph
+ * capture.  Results are those of sf_image_station_loss.
+ */
+#define SF_LOSS_STATIC_MAX_PIXELS (1LL << 28)
+#define SF_LOSS_STATIC_MAX_STATIONS (1 << 20)
+int sf_image_station_loss_static(const float* pred, const float* target, const int* pos,
+                                 const float* runoff, const int* offsets, int S, int B, int H,
+                                 int W, int TH, int TW, int image_metric, float nonzero_weight,
+                                 float zero_threshold, int ksize, int station_metric,
+                                 float image_weight, float station_weight, float* losses,
+                                 float* dpred, void* stream);
 /* mean BCE-with-logits (src/model/gan.py:82,102-108) against `labels` (f32 [n]) or, when
  * labels is NULL, the constant `label`:
  * loss[0] = mean(max(x,0) - x*y + log1p(exp(-|x|))); dx (nullable) = (sigmoid(x) - y)/n. ws: 1 double. */

@@ -6,6 +6,7 @@
 //  * fused Adam, NaN/Inf flag, lon/lat -> pixel map.
 #include "sf_common.h"
 #include "../../include/sfhip.h"
+#include <mutex>
 
 namespace {
 
@@ -384,6 +385,59 @@ __global__ void lonlat_kernel(const double* __restrict__ lon, const double* __re
 }
 
 }  // namespace
+
+// Scratch of sf_image_station_loss_static: the per-block partial sums of one loss call.  Each GPU
+// the library runs on holds its own copy of this array at its own address; host code never uses
+// the array's name as a pointer, only the per-device address hipGetSymbolAddress returned.
+static __device__ __align__(256) double scratch[SF_LOSS_WS_DOUBLES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex scratch_mutex;
+double* scratch_ptr[MAX_DEVICES];     // device address of `scratch` per device, null until first use
+
+// Device address of this device's copy of `scratch` (looked up once per device, with that device current).
+int static_scratch(double** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        sf_set_error("sf_image_station_loss_static: no current device, or device index above %d", MAX_DEVICES - 1);
+        return SF_EINVAL;
+    }
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            sf_set_error("sf_image_station_loss_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+            return SF_ELAUNCH;
+        }
+        scratch_ptr[dev] = (double*)p;
+    }
+    *out = scratch_ptr[dev];
+    return SF_OK;
+}
+}  // namespace
+
+extern "C" int sf_image_station_loss_static(const float* pred, const float* target, const int* pos, const float* runoff,
+                                            const int* offsets, int S, int B, int H, int W, int TH, int TW,
+                                            int image_metric, float nonzero_weight, float zero_threshold, int ksize,
+                                            int station_metric, float image_weight, float station_weight,
+                                            float* losses, float* dpred, void* stream) {
+    SF_REQUIRE(B > 0 && H > 0 && W > 0 && S >= 0, "sf_image_station_loss_static: bad shape");
+    SF_REQUIRE((long long)B * H * W <= SF_LOSS_STATIC_MAX_PIXELS,
+               "sf_image_station_loss_static: %lld prediction pixels, the limit is %lld", (long long)B * H * W,
+               (long long)SF_LOSS_STATIC_MAX_PIXELS);
+    SF_REQUIRE(S <= SF_LOSS_STATIC_MAX_STATIONS, "sf_image_station_loss_static: %d stations, the limit is %d", S,
+               SF_LOSS_STATIC_MAX_STATIONS);
+    double* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != SF_OK) return rc;
+    // every call writes all the partial-sum slots it later reads (nothing has to start at zero), so
+    // the previous call's contents of the array are never seen
+    return sf_image_station_loss(pred, target, pos, runoff, offsets, S, B, H, W, TH, TW, image_metric, nonzero_weight,
+                                 zero_threshold, ksize, station_metric, image_weight, station_weight, losses, dpred, ws,
+                                 stream);
+}
 
 extern "C" int sf_image_station_loss(const float* pred, const float* target, const int* pos, const float* runoff,
                                      const int* offsets, int S, int B, int H, int W, int TH, int TW, int image_metric,

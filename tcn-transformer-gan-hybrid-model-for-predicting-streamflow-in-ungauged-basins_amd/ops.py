@@ -71,7 +71,7 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
            "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
-           "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss",
+           "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss", "sf_image_station_loss_static",
            "sf_bce_logits", "sf_adam", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
            "sf_gather_frames", "sf_date_image_metrics", "sf_date_image_metrics_workspace_bytes", "sf_bn_relu_fwd",
            "sf_relu_dropout_fwd", "sf_relu_dropout_bwd", "sf_gru_save_floats", "sf_gru_fwd", "sf_gru_bwd",
@@ -802,6 +802,23 @@ def image_station_loss(pred, target, pos, runoff, offsets, S, image_metric, nonz
                                        _c_f(image_weight), _c_f(station_weight), _p(losses), _p(dpred), _p(ws),
                                        _stream()), "sf_image_station_loss")
     return losses, dpred
+
+
+def image_station_loss_static(pred, target, pos, runoff, offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
+                              station_metric, image_weight, station_weight, losses, dpred):
+    """sf_image_station_loss_static: as image_station_loss, but the caller passes the outputs
+    (losses f32 [4], dpred like pred) and the partial sums live in the library's own static device
+    array -- the call allocates nothing, here or in the library."""
+    _dev(pred, target, pos, runoff, offsets, losses, dpred,
+         dtypes=[torch.float32, torch.float32, torch.int32, torch.float32, torch.int32, torch.float32, torch.float32])
+    B, _, H, W = pred.shape
+    TH, TW = target.shape[-2], target.shape[-1]
+    if losses.numel() < 4 or dpred.shape != pred.shape:
+        raise RuntimeError("image_station_loss_static: losses needs 4 floats and dpred the shape of pred")
+    _check(lib().sf_image_station_loss_static(_p(pred), _p(target), _p(pos), _p(runoff), _p(offsets), S, B, H, W, TH, TW,
+                                              image_metric, _c_f(nonzero_weight), _c_f(zero_threshold), ksize,
+                                              station_metric, _c_f(image_weight), _c_f(station_weight), _p(losses),
+                                              _p(dpred), _stream()), "sf_image_station_loss_static")
 
 
 def bce_logits(x: torch.Tensor, label: float, labels: Optional[torch.Tensor] = None, need_grad: bool = True):
