@@ -39,7 +39,7 @@ def bench_config(batch):
     }
 
 
-def cpu_baseline(cfg, batches, steps=2, batch=2):
+def cpu_baseline(cfg, batches, steps=3, batch=8):
     """The CPU oracle (oracle/streamflow_oracle.py, kind 'port') doing the identical step in f32
     on the host cores: `batch` samples per step, 1 warm-up + `steps` timed steps."""
     from oracle import streamflow_oracle as O
@@ -131,7 +131,8 @@ def main():
     for i in range(a.warmup):
         ld = step(i)
     # HIP-event pairs cost GPU time, so inside the timed region only the launches of the dominant
-    # kernel are bracketed (3 per step); the other two MFMA kernels are timed in extra steps after it
+    # kernel are bracketed (2 per step: the encoder's second conv and its data gradient); the other
+    # MFMA kernels are timed in extra steps after it
     dom = "conv3_dma_wide_kernel"
     other_tags = ("conv3_dma_res_kernel", "conv3_dma_kernel", "wgrad3_dma_kernel")
     torch.cuda.synchronize()

@@ -359,6 +359,21 @@ int sf_colsum_f32(const float* x, long long M, long long C, float* out, void* st
  * in f32 is off by 5e-5 of its value). */
 int sf_adam(float* p, const float* g, float* m, float* v, long long n, float lr, double beta1,
             double beta2, float eps, float bc1, float bc2, float grad_scale, void* stream);
+/* The same update for optimiser steps that must be skippable without a host synchronisation.  The
+ * reference steps through GradScaler (src/train.py:255-260), which skips optimizer.step() when the
+ * gradients hold Inf/NaN, so the step count of torch.optim.Adam does not advance either.  Here the
+ * count lives on the device: state int32 [2] = {steps taken, steps skipped}, zero before the
+ * first step.  sf_adam_begin, once per optimiser step: found_inf (device int32, nullable) != 0 ->
+ * state[1] += 1, else state[0] += 1.  sf_adam_guarded, once per flat range of that step: nothing
+ * is touched when found_inf[0] != 0; otherwise the Adam update with bias corrections
+ * 1 - beta^t formed in double, t = state[0] + step_offset, and, when shadow_bf16 is not NULL, a
+ * bf16 copy of the updated parameters (the operand the bf16 kernels read) written in the same
+ * pass.  step_offset <= 0: minus the number of optimiser steps this range sat out for want of a
+ * gradient (torch.optim.Adam counts steps per parameter); 0 for a range updated at every step. */
+int sf_adam_begin(int* state, const int* found_inf, void* stream);
+int sf_adam_guarded(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n,
+                    float lr, double beta1, double beta2, float eps, float grad_scale,
+                    const int* state, const int* found_inf, int step_offset, void* stream);
 /* flag[0] |= 1 if any element of x is NaN/Inf (src/train.py:193,198,221) */
 int sf_nan_inf_flag(const float* x, long long n, int* flag, void* stream);
 

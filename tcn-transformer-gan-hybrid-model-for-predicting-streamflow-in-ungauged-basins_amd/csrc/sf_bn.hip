@@ -214,7 +214,7 @@ __global__ __launch_bounds__(BT) void bn_relu_maxpool_fwd_kernel(const T* __rest
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float v = f[e] * sc[e] + sf[e];
-                    mx[e] = v > mx[e] ? v : mx[e];
+                    mx[e] = (v > mx[e] || v != v) ? v : mx[e];   // a NaN wins and stays, as in torch max_pool2d
                 }
             }
             *reinterpret_cast<uint4*>(y + (size_t)rr * C + m.cg * EPC) = Chunk<T>::encode(mx);

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_kernel(C3Params p) {
                 }
                 if (p.act == SF_ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // keeps NaN, like torch.relu
                 } else if (p.act == SF_ACT_LRELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
@@ -507,7 +507,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                 }
                 if (p.act == SF_ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // keeps NaN, like torch.relu
                 } else if (p.act == SF_ACT_LRELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(E_NT, 3) void enc1_kernel(E1Params p) {
                         const unsigned p01 = pack_bf16x2(acc[4 * g], acc[4 * g + 1]), p23 = pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]);
                         const float v0 = __uint_as_float(p01 << 16) * sc[kt] + sf[kt], v1 = __uint_as_float(p01 & 0xffff0000u) * sc[kt] + sf[kt];
                         const float v2 = __uint_as_float(p23 << 16) * sc[kt] + sf[kt], v3 = __uint_as_float(p23 & 0xffff0000u) * sc[kt] + sf[kt];
-                        const float mx = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), 0.f);   // ReLU, then max
+                        float mx = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), 0.f);   // ReLU, then max
+                        if ((v0 != v0) | (v1 != v1) | (v2 != v2) | (v3 != v3)) mx = __builtin_nanf("");   // torch keeps a NaN
                         const int wx = (cur.x0 >> 1) + 2 * g + h;
                         if (full || (wy < PH && wx < PWd)) yrow[(size_t)2 * g * p.K] = (bf16)mx;
                     }

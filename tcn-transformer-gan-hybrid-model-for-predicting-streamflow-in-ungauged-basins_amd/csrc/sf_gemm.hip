@@ -352,7 +352,7 @@ __device__ __forceinline__ void gemm_body(const KParams& p, const int block_id, 
                     } else {
                         if (p.act == SF_ACT_RELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // keeps NaN, like torch.relu
                         } else if (p.act == SF_ACT_LRELU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];

@@ -326,6 +326,62 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Adam driven by device-side state: state[0] = number of steps taken, state[1] = steps skipped.
+// adam_begin_kernel advances one of the two depending on found_inf; adam_guarded_kernel leaves
+// everything untouched when found_inf is set, else forms the bias corrections from state[0] (in
+// double, as torch.optim.Adam forms them on the host) and optionally writes a bf16 copy of the
+// updated parameters.
+__global__ void adam_begin_kernel(int* __restrict__ state, const int* __restrict__ found_inf) {
+    if (found_inf && found_inf[0] != 0) state[1] += 1;
+    else state[0] += 1;
+}
+
+__global__ void adam_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, bf16* __restrict__ shadow, long long n, float lr, double beta1,
+                                    double beta2, float eps, float gs, const int* __restrict__ state,
+                                    const int* __restrict__ found_inf, int step_offset) {
+    if (found_inf && found_inf[0] != 0) return;
+    const int t = max(state[0] + step_offset, 1);
+    const float bc1 = (float)(1.0 - pow(beta1, (double)t)), bc2 = (float)(1.0 - pow(beta2, (double)t));
+    const float b1 = (float)beta1, b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    const float step = lr / bc1;
+    const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    // four elements per thread and iteration when the range allows 16-byte accesses
+    const bool vec = ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0 && ((uintptr_t)shadow % 8) == 0;
+    const long long n4 = vec ? n / 4 : 0;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+        float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], p4 = reinterpret_cast<float4*>(p)[i];
+        float* gp = const_cast<float*>(&g4.x); float* mp = &m4.x; float* vp = &v4.x; float* pp = &p4.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = gp[e] * gs;
+            mp[e] = b1 * mp[e] + omb1 * gi;
+            vp[e] = b2 * vp[e] + omb2 * gi * gi;
+            pp[e] -= step * mp[e] / (sqrtf(vp[e]) * inv_sqrt_bc2 + eps);
+        }
+        reinterpret_cast<float4*>(m)[i] = m4;
+        reinterpret_cast<float4*>(v)[i] = v4;
+        reinterpret_cast<float4*>(p)[i] = p4;
+        if (shadow) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)pp[e];
+            reinterpret_cast<bf16x4*>(shadow)[i] = o;
+        }
+    }
+    for (long long i = 4 * n4 + blockIdx.x * (long long)NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float pi = p[i] - step * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        p[i] = pi;
+        if (shadow) shadow[i] = (bf16)pi;
+    }
+}
+
 // out[c] = sum_m x[m][c].  A block owns 32 columns; its 8 row groups each take every 8th row,
 // four loads in flight (rows past the end read row M-1 with weight 0), and are folded through
 // LDS in a fixed order.  Both shapes of the Linear bias gradients are latency bound: [32 x
@@ -490,6 +546,26 @@ extern "C" int sf_adam(float* p, const float* g, float* m, float* v, long long n
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, lr, (float)beta1,
                        (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, bc1, bc2, grad_scale);
     SF_LAUNCH_CHECK("sf_adam");
+    return SF_OK;
+}
+
+extern "C" int sf_adam_begin(int* state, const int* found_inf, void* stream) {
+    SF_REQUIRE(state, "sf_adam_begin: null state");
+    hipLaunchKernelGGL(adam_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, found_inf);
+    SF_LAUNCH_CHECK("sf_adam_begin");
+    return SF_OK;
+}
+
+extern "C" int sf_adam_guarded(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n, float lr,
+                               double beta1, double beta2, float eps, float grad_scale, const int* state,
+                               const int* found_inf, int step_offset, void* stream) {
+    SF_REQUIRE(p && g && m && v && state && n > 0 && step_offset <= 0, "sf_adam_guarded: bad arguments");
+    SF_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "sf_adam_guarded: betas must lie in [0, 1)");
+    long long work = (n + 3) / 4;
+    int grid = (int)((work + NT - 1) / NT); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(adam_guarded_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n,
+                       lr, beta1, beta2, eps, grad_scale, state, found_inf, step_offset);
+    SF_LAUNCH_CHECK("sf_adam_guarded");
     return SF_OK;
 }
 

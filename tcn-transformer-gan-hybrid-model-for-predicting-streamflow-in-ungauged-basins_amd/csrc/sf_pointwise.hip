@@ -221,7 +221,7 @@ __global__ void bn_relu_avgpool_fwd_kernel(const T* __restrict__ x, const float*
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         const float v = f[e] * sc[e] + sf[e];
-                        acc[e] += v > 0.f ? v : 0.f;
+                        acc[e] += v < 0.f ? 0.f : v;   // ReLU that keeps NaN
                     }
                 }
             const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const float* __re
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float v = x[i];
         const float m = (p > 0.f && rand_u(seed, (unsigned long long)i) < p) ? 0.f : keep;
-        y[i] = v > 0.f ? v * m : 0.f;
+        y[i] = v < 0.f ? 0.f : v * m;   // ReLU that keeps NaN
     }
 }
 __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,

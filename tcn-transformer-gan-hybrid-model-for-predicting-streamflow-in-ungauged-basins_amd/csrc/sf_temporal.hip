@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NT_FWD) void transformer_fwd_kernel(const float* __
         dot_row_tokens(W1 + (size_t)f * D, x1, D, D, T, dacc);
         for (int t = 0; t < T; ++t) {
             float v = dacc[t] + bb;
-            v = v > 0.f ? v * drop_mask(p, seed, b, 2, t * F + f) : 0.f;
+            v = v < 0.f ? 0.f : v * drop_mask(p, seed, b, 2, t * F + f);   // ReLU that keeps NaN
             hd[t * F + f] = v;
             if (sv) s_hd[t * F + f] = v;
         }

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(UT) void upconv3_fwd_kernel(const float* __restrict
         }
         if (act == SF_ACT_RELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+            for (int e = 0; e < 8; ++e) o[e] = o[e] < 0.f ? 0.f : o[e];   // keeps NaN, like torch.relu
         }
         store8<T>(orow + (size_t)ox * K, o);
         a0 = a1;

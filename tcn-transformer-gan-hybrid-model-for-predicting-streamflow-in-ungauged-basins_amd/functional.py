@@ -163,13 +163,17 @@ class LinearFn(torch.autograd.Function):
     (src/model/transformer_module.py:73 / src/model/lstm_module.py:36, src/model/__init__.py:92-95)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, cdtype):
+    def forward(ctx, x, W, b, cdtype, w_shadow=None):
+        # w_shadow: a current bf16 copy of W (ops.shadow_if_current) that saves the cast
         M, K = x.shape
         Nf = W.shape[0]
         if K % 8 or Nf % 8:
             raise NotImplementedError(f"Linear {K}->{Nf}: both sizes must be multiples of 8 on the HIP path")
         xt = ops.cast(x.contiguous().float(), cdtype)
-        Wt = ops.cast(W.detach().contiguous(), cdtype)
+        if w_shadow is not None and cdtype == torch.bfloat16 and w_shadow.shape == W.shape:
+            Wt = w_shadow
+        else:
+            Wt = ops.cast(W.detach().contiguous(), cdtype)
         bk = 32 if cdtype == torch.bfloat16 else 16
         nsplit = max(1, min(256, K // (bk * 16)))
         y = _split_gemm(Wt, xt, Nf, M, K, K, K, Nf, False, nsplit, b.detach().contiguous() if b is not None else None)
@@ -193,7 +197,13 @@ class LinearFn(torch.autograd.Function):
             ops.linear_gemm(dyt, xt, dW, Nf, K, M, Nf, K, K, True, True, ops.OUT_IJ, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum_f32(dy)
-        return dx, dW, db, None
+        return dx, dW, db, None, None
+
+
+def linear(x, lin, cdtype):
+    """LinearFn on an nn.Linear's parameters, reading the weight's bf16 shadow when it is current."""
+    sh = ops.shadow_if_current(lin.weight) if cdtype == torch.bfloat16 else None
+    return LinearFn.apply(x, lin.weight, lin.bias, cdtype, sh)
 
 
 # ------------------------------------------------------------------------------ temporal modules
@@ -388,11 +398,13 @@ class DiscriminatorFn(torch.autograd.Function):
     statistics and updates its running buffers, as the reference never puts D in eval mode."""
 
     @staticmethod
-    def forward(ctx, x, cdtype, training, reuse, w1, b1, *rest):
+    def forward(ctx, x, cdtype, training, reuse, record, w1, b1, *rest):
         # rest = 3 x (w, b, gamma, beta, rm, rv) + (w5, b5)
-        # `reuse`: the record of an earlier forward of the SAME input with the SAME parameters
-        # (DiscriminatorFn.last_record): nothing is recomputed, only the BatchNorm running
-        # statistics are updated again, as a second forward call would.
+        # `record`: None, or a dict that receives the activations of this forward.
+        # `reuse`: the record of an earlier training-mode forward of the SAME input with the SAME
+        # parameters: nothing is recomputed, only the BatchNorm running statistics are updated
+        # again, as a second forward call would.
+        # training=False: BatchNorm normalises with its running statistics and updates nothing.
         if reuse is not None:
             if tuple(reuse["x"].shape) != tuple(x.shape):
                 raise ValueError("DiscriminatorFn: the reused forward record belongs to another input shape")
@@ -405,6 +417,7 @@ class DiscriminatorFn(torch.autograd.Function):
             ctx.x, ctx.acts, ctx.zs, ctx.sts = reuse["x"], reuse["acts"], reuse["zs"], reuse["sts"]
             ctx.params = (w1, b1, *rest)
             ctx.cdtype = cdtype
+            ctx.training = True
             return reuse["out"].clone()
         N, _, H, W = x.shape
         x = x.contiguous().float()
@@ -426,9 +439,11 @@ class DiscriminatorFn(torch.autograd.Function):
             z = torch.empty((N, oh, ow, K), device=x.device, dtype=cdtype)
             ops.conv_fprop(y, wp, z, _s2_geom(N, ih, iw, C, oh, ow), K, bias=b.detach().contiguous())
             M = N * oh * ow
-            ws = ops.bn_ws(K, x.device)
-            ops.bn_stats(z, M, K, ws)
-            st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, True)
+            ws = None
+            if training:
+                ws = ops.bn_ws(K, x.device)
+                ops.bn_stats(z, M, K, ws)
+            st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, training)
             y = ops.bn_lrelu_fwd(z, st)
             zs.append(z)
             wss.append(ws)
@@ -440,10 +455,10 @@ class DiscriminatorFn(torch.autograd.Function):
         ctx.x, ctx.acts, ctx.zs, ctx.sts = x, acts, zs, sts
         ctx.params = (w1, b1, *rest)
         ctx.cdtype = cdtype
-        DiscriminatorFn.last_record = {"x": x, "acts": acts, "zs": zs, "sts": sts, "wss": wss, "out": out}
+        ctx.training = training
+        if record is not None:      # the caller asked for the activations (to pass them back as `reuse`)
+            record.update({"x": x, "acts": acts, "zs": zs, "sts": sts, "wss": wss, "out": out})
         return out
-
-    last_record = None   # activations of the most recent full forward (see `reuse`)
 
     @staticmethod
     def backward(ctx, dout):
@@ -456,7 +471,7 @@ class DiscriminatorFn(torch.autograd.Function):
         y4 = acts[3]
         # parameter gradients are skipped as a whole when no parameter asks for one (the trainer
         # turns them off for batches whose discriminator gradients would be zeroed unused)
-        need_w = any(ctx.needs_input_grad[4:])
+        need_w = any(ctx.needs_input_grad[5:])
         if need_w:
             dw5, db5 = ops.conv_k1_bwd_weight(y4, dout, w5.shape[1], 4, 1)
             grads[2 + 18], grads[2 + 19] = dw5, db5
@@ -466,7 +481,7 @@ class DiscriminatorFn(torch.autograd.Function):
             z, st, yin = zs[i], sts[i], acts[i]
             K, C = wt.shape[0], yin.shape[-1]
             ih, iw, oh, ow = yin.shape[1], yin.shape[2], z.shape[1], z.shape[2]
-            dz, dgamma, dbeta = ops.bn_backward(2, z, dy, st, gamma.detach(), K, True)
+            dz, dgamma, dbeta = ops.bn_backward(2, z, dy, st, gamma.detach(), K, ctx.training)
             if need_w:
                 dw = torch.empty_like(wt)
                 ops.wgrad4x4s2(yin, dz, dw)
@@ -490,7 +505,7 @@ class DiscriminatorFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.dconv1_bwd_data(dy, w1.detach().contiguous(), x.shape[2], x.shape[3])
         ctx.x = ctx.acts = ctx.zs = ctx.sts = None
-        return (dx, None, None, None, *grads)
+        return (dx, None, None, None, None, *grads)
 
 
 # ------------------------------------------------------------------------------ losses

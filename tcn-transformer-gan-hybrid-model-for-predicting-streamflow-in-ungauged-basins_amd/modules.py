@@ -135,8 +135,7 @@ class TransformerModule(nn.Module):
         _need_cuda(x, "TransformerModule")
         B, T, _ = x.shape
         if self.input_proj is not None:
-            x = SF.LinearFn.apply(x.reshape(B * T, -1), self.input_proj.weight, self.input_proj.bias,
-                                  SF.compute_dtype()).view(B, T, -1)
+            x = SF.linear(x.reshape(B * T, -1), self.input_proj, SF.compute_dtype()).view(B, T, -1)
         p = self.dropout if self.training else 0.0
         seed = SF.new_seed() if p > 0 else 0
         return SF.TransformerStackFn.apply(x, self.pos_encoder.pe[0], self.num_heads, p, seed,
@@ -173,8 +172,7 @@ class LSTMModule(nn.Module):
         _need_cuda(x, "LSTMModule")
         B, T, _ = x.shape
         if self.input_proj is not None:
-            x = SF.LinearFn.apply(x.reshape(B * T, -1), self.input_proj.weight, self.input_proj.bias,
-                                  SF.compute_dtype()).view(B, T, -1)
+            x = SF.linear(x.reshape(B * T, -1), self.input_proj, SF.compute_dtype()).view(B, T, -1)
         p = self.dropout if self.training else 0.0
         seed = SF.new_seed() if p > 0 else 0
         return SF.LstmFn.apply(x, self.num_layers, p, seed, *self._weights())
@@ -246,8 +244,7 @@ class StreamflowPredictionModel(nn.Module):
         encoded = self.cnn_encoder(images.reshape(B * T, C, H, W))
         _, oc, he, we = encoded.shape
         t_out = self.temporal_module(encoded.reshape(B, T, -1))
-        sp = SF.LinearFn.apply(t_out, self.temporal_to_spatial.weight, self.temporal_to_spatial.bias,
-                               SF.compute_dtype())
+        sp = SF.linear(t_out, self.temporal_to_spatial, SF.compute_dtype())
         return self.decoder(sp.view(B, oc, he, we))
 
     def forward_windows(self, frames: torch.Tensor, starts: torch.Tensor, window: int) -> torch.Tensor:
@@ -268,8 +265,7 @@ class StreamflowPredictionModel(nn.Module):
         win = torch.empty((B * window, F), device=frames.device, dtype=torch.float32)
         SF.ops.gather_frames(encoded, F, N, rows.contiguous(), F, win)
         t_out = self.temporal_module(win.view(B, window, F))
-        sp = SF.LinearFn.apply(t_out, self.temporal_to_spatial.weight, self.temporal_to_spatial.bias,
-                               SF.compute_dtype())
+        sp = SF.linear(t_out, self.temporal_to_spatial, SF.compute_dtype())
         return self.decoder(sp.view(B, oc, he, we))
 
     def get_num_parameters(self) -> int:
@@ -296,23 +292,31 @@ class PatchDiscriminator(nn.Module):
             conv_block(hc, hc * 2), conv_block(hc * 2, hc * 4), conv_block(hc * 4, hc * 8),
             nn.Conv2d(hc * 8, 1, kernel_size=4, stride=1, padding=1))
 
-    def forward(self, x: torch.Tensor, reuse=None) -> torch.Tensor:
-        """`reuse`: the `last_record` taken after an earlier call on the same input while the
-        parameters have not changed -- the forward is then not recomputed (the BatchNorm running
-        statistics still advance as for a second call)."""
+    def forward(self, x: torch.Tensor, reuse=None, keep_record: bool = False) -> torch.Tensor:
+        """Training mode: BatchNorm uses batch statistics and updates its running buffers; eval
+        mode: running statistics, no updates (nn.BatchNorm2d semantics; the reference's trainer
+        never leaves training mode, src/train.py:213,234-236).
+        keep_record: keep this call's activations on `self.last_record` until the next call.
+        `reuse`: such a record, taken from an earlier training-mode call on the same input while
+        the parameters have not changed -- the forward is then not recomputed (the BatchNorm
+        running statistics still advance as for a second call)."""
         _need_cuda(x, "PatchDiscriminator")
+        if reuse is not None and not self.training:
+            raise RuntimeError("PatchDiscriminator: a forward record can only be reused in training mode")
         m = self.model
         ps = [m[0].weight, m[0].bias]
         for i in (2, 3, 4):
             conv, bn = m[i][0], m[i][1]
             ps += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-            bn.num_batches_tracked += 1
+            if self.training:
+                bn.num_batches_tracked += 1
         ps += [m[5].weight, m[5].bias]
-        out = SF.DiscriminatorFn.apply(x.float(), SF.compute_dtype(), True, reuse, *ps)
-        if reuse is None:
-            self.last_record = SF.DiscriminatorFn.last_record
-            SF.DiscriminatorFn.last_record = None
+        record = {} if (keep_record and reuse is None) else None
+        out = SF.DiscriminatorFn.apply(x.float(), SF.compute_dtype(), self.training, reuse, record, *ps)
+        self.last_record = record
         return out
+
+    last_record = None
 
 
 class _BceWithLogits(nn.Module):

@@ -72,7 +72,7 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss", "sf_image_station_loss_static",
-           "sf_bce_logits", "sf_adam", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
+           "sf_bce_logits", "sf_adam", "sf_adam_begin", "sf_adam_guarded", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
            "sf_gather_frames", "sf_date_image_metrics", "sf_date_image_metrics_workspace_bytes", "sf_bn_relu_fwd",
            "sf_relu_dropout_fwd", "sf_relu_dropout_bwd", "sf_gru_save_floats", "sf_gru_fwd", "sf_gru_bwd",
            "sf_attn_save_floats", "sf_attn_fwd", "sf_attn_bwd", "sf_token_outer4"]
@@ -371,6 +371,41 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
     _check(lib().sf_cast(_p(x), _p(out), code_of(dtype), _c_ll(x.numel()), _stream()), "sf_cast")
     return out
+
+
+# bf16 shadow copies of big f32 parameters (the 262144-wide Linear weights): written by the fused
+# Adam kernel together with the parameter, so the bf16 kernels need no 134 MB cast per call.  A
+# shadow counts as current while the parameter has not been written through torch since (its
+# version counter) and still lives at the same address.
+WEIGHT_EPOCH = 0     # bumped whenever an optimiser kernel rewrites parameters behind torch's back
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def _shadow_key(p: torch.Tensor):
+    return (p._version, p.data_ptr(), tuple(p.shape))
+
+
+def shadow_if_current(p: torch.Tensor) -> Optional[torch.Tensor]:
+    sh = getattr(p, "_sf_shadow", None)
+    return sh if sh is not None and getattr(p, "_sf_shadow_key", None) == _shadow_key(p) else None
+
+
+def weight_shadow(p: torch.Tensor) -> torch.Tensor:
+    """The current bf16 shadow of parameter p, (re)built by a cast when missing or stale."""
+    sh = shadow_if_current(p)
+    if sh is None:
+        sh = cast(p.detach().contiguous(), torch.bfloat16)
+        p._sf_shadow = sh
+        p._sf_shadow_key = _shadow_key(p)
+    return sh
+
+
+def mark_shadow_current(p: torch.Tensor):
+    p._sf_shadow_key = _shadow_key(p)
 
 
 # ------------------------------------------------------------------------------ batch norm family
@@ -836,6 +871,24 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
     _check(lib().sf_adam(_p(p), _p(g), _p(m), _p(v), _c_ll(p.numel()), _c_f(lr), ctypes.c_double(beta1), ctypes.c_double(beta2), _c_f(eps),
                          _c_f(bc1), _c_f(bc2), _c_f(grad_scale), _stream()), "sf_adam")
+
+
+def adam_begin(state: torch.Tensor, found_inf: Optional[torch.Tensor]):
+    """state int32 [2] (steps taken, steps skipped): one of the two advances, by found_inf."""
+    _dev(state, found_inf, dtypes=[torch.int32, torch.int32])
+    _check(lib().sf_adam_begin(_p(state), _p(found_inf), _stream()), "sf_adam_begin")
+
+
+def adam_guarded(p, g, m, v, lr, beta1, beta2, eps, state, found_inf=None, grad_scale=1.0, shadow=None, step_offset=0):
+    """Adam update of a flat range with the step count read from `state` on the device; a no-op
+    when found_inf[0] != 0.  shadow: optional bf16 tensor of p's size that receives the new values."""
+    _dev(p, g, m, v, state, found_inf, shadow,
+         dtypes=[torch.float32] * 4 + [torch.int32, torch.int32, torch.bfloat16])
+    if shadow is not None and shadow.numel() != p.numel():
+        raise RuntimeError("adam_guarded: the bf16 shadow must have the parameter range's size")
+    _check(lib().sf_adam_guarded(_p(p), _p(g), _p(m), _p(v), _p(shadow), _c_ll(p.numel()), _c_f(lr), ctypes.c_double(beta1),
+                                 ctypes.c_double(beta2), _c_f(eps), _c_f(grad_scale), _p(state), _p(found_inf),
+                                 int(step_offset), _stream()), "sf_adam_guarded")
 
 
 def nan_inf_flag(x: torch.Tensor, flag: torch.Tensor):

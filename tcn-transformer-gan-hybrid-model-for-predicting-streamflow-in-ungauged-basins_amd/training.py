@@ -1,19 +1,25 @@
-"""Training-step driver: the counterpart of Trainer.train_epoch (src/train.py:154-305) for the
-HIP modules, one process per GPU.
+"""Training driver: the counterpart of Trainer (src/train.py:29-494) for the HIP modules, one
+process per GPU.
 
-It reproduces the reference's step semantics exactly (generator loss = combined loss +
-gan_weight * BCE(D(pred), 1) back-propagated THROUGH an unfrozen discriminator; discriminator
-loss every third batch on top; both optimisers step on (batch_idx+1) % accum == 0, the
-discriminator's only when batch_idx % 3 == 0; then both gradient sets are zeroed) and adds
-what the reference lacks: parameters and Adam moments live in flat buffers so that one fused
-kernel launch updates a whole network, gradients are taken as the backward kernels produce them
-(no per-parameter accumulate launches), and data-parallel gradient averaging over RCCL reduces
-the two 134 MB Linear weight gradients in place as soon as they exist and everything else as
-one flat buffer.
+train_step reproduces the reference's batch-loop semantics exactly (generator loss = combined
+loss + gan_weight * BCE(D(pred), 1) back-propagated THROUGH an unfrozen discriminator;
+discriminator loss every third batch on top; both optimisers step on (batch_idx+1) % accum == 0,
+the discriminator's only when batch_idx % 3 == 0; then both gradient sets are zeroed);
+train_epoch / train / validate keep the reference's return values, log lines and checkpoint files.
+Added to what the reference has: parameters and Adam moments live in flat buffers so that one
+fused kernel launch updates a whole network, gradients are taken as the backward kernels produce
+them (no per-parameter accumulate launches), the Inf/NaN checks and the GradScaler-style step skip
+run on the device without host synchronisation, and data-parallel gradient averaging over RCCL
+reduces the two 134 MB Linear weight gradients in place as soon as they exist and everything else
+as one flat buffer per network.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+import logging
+import os
+from datetime import datetime
+from pathlib import Path
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -28,16 +34,25 @@ _ALIGN = 64  # floats: every parameter starts on a 256-byte boundary of the flat
 class FlatAdam:
     """Adam (torch.optim.Adam defaults: eps 1e-8, no weight decay, src/train.py:80-91) over flat
     f32 buffers: parameters and both moments of one network live in one buffer each (parameters
-    are views into it), so a whole network is updated by one sf_adam launch.
+    are views into it), so a whole network is updated by one sf_adam_guarded launch.
 
     Gradients are not views: with .grad unset, autograd hands every parameter the tensor its
     backward kernel produced instead of launching an accumulate kernel per parameter per backward
     pass.  gather() then copies the small gradients into one flat buffer (a multi-tensor copy;
     that buffer is also what data-parallel ranks all-reduce in one call), while parameters of at
     least `big_numel` elements sit at the end of the layout and are updated straight from their
-    own gradient tensors (and all-reduced in place)."""
+    own gradient tensors (and all-reduced in place).
 
-    def __init__(self, module: nn.Module, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, big_numel: int = 1 << 22):
+    A parameter without a gradient is left untouched by step(), moments included, and its own
+    step count does not advance, as in torch.optim.Adam (which counts steps per parameter; the
+    one case not reproduced is a step that is both skipped and missed by the parameter).
+    The step count lives on the device (state[0]) so that a step can be
+    skipped by a device-side flag (`found_inf`) without a host synchronisation; state[1] counts
+    the skipped steps.  Big parameters get a bf16 shadow copy written by the same kernel when
+    `shadow_big` is set: the 262144-wide Linear layers read it instead of casting 134 MB per call."""
+
+    def __init__(self, module: nn.Module, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, big_numel: int = 1 << 22,
+                 shadow_big: bool = False):
         params = [p for p in module.parameters() if p.requires_grad]
         self.small = [p for p in params if p.numel() < big_numel]
         self.big = [p for p in params if p.numel() >= big_numel]
@@ -52,6 +67,7 @@ class FlatAdam:
         self.m = torch.zeros(total, device=dev, dtype=torch.float32)
         self.v = torch.zeros(total, device=dev, dtype=torch.float32)
         self.gsmall = torch.zeros(self.n_small, device=dev, dtype=torch.float32)
+        self.state = torch.zeros(2, device=dev, dtype=torch.int32)
         self.ranges = []
         for p, o in zip(self.params, offs):
             n = p.numel()
@@ -59,32 +75,69 @@ class FlatAdam:
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = None
             self.ranges.append((o, n))
-        self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.shadow_big = bool(shadow_big) and dev.type == "cuda"
+        self._spans: List[Tuple[int, int, int]] = []
+        self._calls = 0                          # step() calls so far
+        self._seen = [0] * len(self.params)      # step() calls in which the parameter had a gradient
+
+    @property
+    def t(self) -> int:
+        """Optimiser steps taken so far (host-synchronising read of the device counter)."""
+        return int(self.state[0].item())
+
+    @property
+    def skipped(self) -> int:
+        return int(self.state[1].item())
 
     def gather(self):
-        """Small gradients -> self.gsmall (zeros for a parameter that received none)."""
-        dst, src = [], []
-        for p, (o, n) in zip(self.small, self.ranges):
+        """Small gradients -> self.gsmall (zeros for a parameter that received none, so that the
+        buffer a data-parallel all-reduce sends is defined everywhere); records the spans of
+        parameters that did receive one for step()."""
+        dst, src, spans = [], [], []
+        for i, (p, (o, n)) in enumerate(zip(self.small, self.ranges)):
             if p.grad is None:
                 self.gsmall[o:o + n].zero_()
+                continue
+            dst.append(self.gsmall[o:o + n].view(p.shape))
+            src.append(p.grad)
+            end = min((o + n + _ALIGN - 1) // _ALIGN * _ALIGN, self.n_small)
+            off = self._seen[i] - self._calls      # minus the steps this parameter sat out
+            if spans and spans[-1][1] == o and spans[-1][2] == off:
+                spans[-1] = (spans[-1][0], end, off)
             else:
-                dst.append(self.gsmall[o:o + n].view(p.shape))
-                src.append(p.grad)
+                spans.append((o, end, off))
         if dst:
             torch._foreach_copy_(dst, src)
+        self._spans = spans
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, found_inf: Optional[torch.Tensor] = None):
         """One Adam update from the gathered small gradients and the big parameters' own gradient
-        tensors (a big parameter without a gradient is skipped, like torch.optim.Adam does)."""
-        self.t += 1
+        tensors; skipped as a whole (step count included) when found_inf[0] != 0 on the device."""
         b1, b2 = self.betas
-        S = self.n_small
-        if S:
-            ops.adam(self.flat[:S], self.gsmall, self.m[:S], self.v[:S], self.lr, b1, b2, self.eps, self.t, grad_scale)
-        for p, (o, n) in zip(self.big, self.ranges[len(self.small):]):
+        ops.adam_begin(self.state, found_inf)
+        for (a, e, off) in self._spans:     # alignment gaps inside a span hold zero gradients and zero parameters
+            ops.adam_guarded(self.flat[a:e], self.gsmall[a:e], self.m[a:e], self.v[a:e], self.lr, b1, b2, self.eps,
+                             self.state, found_inf, grad_scale, step_offset=off)
+        ns = len(self.small)
+        for i, (p, (o, n)) in enumerate(zip(self.big, self.ranges[ns:])):
+            if p.grad is None:
+                continue
+            shadow = ops.weight_shadow(p) if self.shadow_big else None
+            ops.adam_guarded(self.flat[o:o + n], p.grad.contiguous().view(-1), self.m[o:o + n], self.v[o:o + n], self.lr,
+                             b1, b2, self.eps, self.state, found_inf, grad_scale, shadow=shadow,
+                             step_offset=self._seen[ns + i] - self._calls)
+            if shadow is not None:
+                ops.mark_shadow_current(p)
+        self._calls += 1
+        for i, p in enumerate(self.params):
             if p.grad is not None:
-                ops.adam(self.flat[o:o + n], p.grad.contiguous().view(-1), self.m[o:o + n], self.v[o:o + n], self.lr,
-                         b1, b2, self.eps, self.t, grad_scale)
+                self._seen[i] += 1
+        ops.bump_weight_epoch()
+
+    def grads(self) -> List[torch.Tensor]:
+        """The tensors an Inf/NaN check of this step's gradients has to look at (after gather())."""
+        return [self.gsmall] + [p.grad.contiguous().view(-1) for p in self.big if p.grad is not None]
 
     def zero_grad(self):
         for p in self.params:
@@ -107,7 +160,9 @@ class FlatAdam:
                 raise RuntimeError(f"optimiser state for {k} is missing or has the wrong shape")
             self.m[o:o + n].copy_(state["exp_avg"][k].reshape(-1))
             self.v[o:o + n].copy_(state["exp_avg_sq"][k].reshape(-1))
-        self.t = int(state["t"])
+        self.state[0] = int(state["t"])
+        self._calls = int(state["t"])
+        self._seen = [self._calls] * len(self.params)
 
     def range_of(self, p: torch.Tensor):
         for q, r in zip(self.params, self.ranges):
@@ -116,36 +171,56 @@ class FlatAdam:
         raise KeyError("parameter not managed by this optimiser")
 
 
+# flag slots of Trainer.nan_flags, one per check of src/train.py:193-199,221-222 (+ the gradients)
+_FLAG_IMAGES, _FLAG_PRED, _FLAG_LOSS, _FLAG_GRADS = 0, 1, 2, 3
+_FLAG_WARNINGS = {_FLAG_IMAGES: "NaN or Inf found in input images!",
+                  _FLAG_PRED: "NaN or Inf found in model predictions!",
+                  _FLAG_LOSS: "NaN or Inf found in loss!"}
+
+
 class Trainer:
-    def __init__(self, config: Dict, device: str = "cuda", distributed: Optional[bool] = None,
+    def __init__(self, config: Dict, device: Optional[str] = None, distributed: Optional[bool] = None,
                  model_path: Optional[str] = None):
         self.config = config
+        if device is None:
+            device = config.get("train", {}).get("device", "cuda")
         self.device = torch.device(device)
         mcfg, scfg = config.get("model", {}), config.get("system", {})
+        self.logger = logging.getLogger("Trainer")
         self.model = StreamflowPredictionModel(config).to(self.device)
-        if model_path is not None:      # Trainer(config, model_path), src/train.py:49-51: a bare generator state_dict
+        if model_path is not None and os.path.exists(model_path):   # src/train.py:49-51: a bare generator state_dict
+            self.logger.info(f"Loading model from {model_path}")
             self.model.load_state_dict(_host_load(model_path))
         self.loss_fn = CombinedLoss(config)
         lr = config.get("train", {}).get("lr", 1e-4)
         self.use_gan = bool(mcfg.get("use_gan", False))
         self.gan_weight = mcfg.get("gan_weight", 0.1)
         self.use_amp = bool(scfg.get("mixed_precision", True))
-        self.accum = int(scfg.get("grad_accum_steps", 1))
+        self.accum = self.grad_accum_steps = int(scfg.get("grad_accum_steps", 1))
         self.d_update_interval = 3  # src/train.py:101
+        self.log_interval = int(scfg.get("log_interval", 10))
         big = int(scfg.get("big_grad_numel", 1 << 22))  # gradients this large skip the flat gradient buffer
-        self.opt_g = FlatAdam(self.model, lr, big_numel=big)
+        self.opt_g = FlatAdam(self.model, lr, big_numel=big, shadow_big=self.use_amp)
         if self.use_gan:
             self.discriminator = PatchDiscriminator(1, 64).to(self.device)
             self.gan_loss_fn = GANLoss(lambda_gan=self.gan_weight, lambda_pixel=1.0)
             self.opt_d = FlatAdam(self.discriminator, lr * 0.2, betas=(0.5, 0.999), big_numel=big)
+        self.epoch = 0
+        self.best_loss = float("inf")
         self.batch_idx = 0
+        self.epoch_batches: Optional[int] = None   # batches per epoch when driven by train_epoch
         self._d_req = True
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.world = dist.get_world_size() if self.distributed else 1
-        self.nan_flag = torch.zeros(1, device=self.device, dtype=torch.int32)
+        self.nan_flags = torch.zeros(4, device=self.device, dtype=torch.int32)
+        self.found_inf = torch.zeros(1, device=self.device, dtype=torch.int32)
         self._pending: List = []
         self._reduce_now = False
         if self.distributed:
+            # RCCL works on device tensors and is ordered against streams; any other backend (gloo on
+            # hosts without a device transport) gets the gradients staged through host memory
+            self._device_collectives = dist.get_backend() == "nccl"
+            self._comm_stream = torch.cuda.Stream(device=self.device) if self._device_collectives else None
             self._broadcast_initial_state()
             self._install_early_reduce()
 
@@ -162,36 +237,70 @@ class Trainer:
         with torch.no_grad():
             for group in by_dtype.values():     # one collective per dtype, not one per tensor
                 flat = torch.cat([t.reshape(-1) for t in group])
-                torch.cuda.synchronize(self.device)
-                dist.broadcast(flat, 0)
-                torch.cuda.synchronize(self.device)
+                if self._device_collectives:
+                    dist.broadcast(flat, 0)     # stream ordered: the copies below queue behind it
+                else:
+                    host = flat.cpu()
+                    dist.broadcast(host, 0)
+                    flat.copy_(host)
                 off = 0
                 for t in group:
                     t.copy_(flat[off:off + t.numel()].view_as(t))
                     off += t.numel()
+        ops.bump_weight_epoch()
+
+    def _all_reduce(self, t: torch.Tensor):
+        """Sum `t` over the ranks, in place.  RCCL: asynchronous on the communication stream, which
+        first waits for everything queued so far on the stream that produced `t` (the stream that
+        is current here: inside an autograd hook that is the stream of the backward kernel whose
+        output `t` is); _wait_reduces later makes the compute stream wait for the result.  Other
+        backends: staged through host memory and finished before returning (the host copy
+        synchronises with the producing stream), so no device tensor ever crosses the backend."""
+        if self._device_collectives:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ready)
+                work = dist.all_reduce(t, async_op=True)
+            t.record_stream(self._comm_stream)
+            self._pending.append(work)
+        else:
+            host = t.detach().to("cpu")
+            dist.all_reduce(host)
+            t.copy_(host, non_blocking=False)
+
     def _install_early_reduce(self):
         """The two 262144-wide Linear weights are 95 % of the gradient bytes; their gradients are
         complete long before the encoder's backward finishes, so each is all-reduced in place
-        from a post-accumulate hook and overlaps with the remaining backward kernels."""
+        from a post-accumulate hook and overlaps with the remaining backward kernels.  Hooks run
+        in the order of the backward graph, which is the same on every rank."""
         for p in self.opt_g.big:
             def hook(param):
                 if self._reduce_now:
-                    self._pending.append(dist.all_reduce(param.grad, async_op=True))
+                    self._all_reduce(param.grad)
 
             p.register_post_accumulate_grad_hook(hook)
 
     def _wait_reduces(self):
         for w in self._pending:
-            w.wait()
+            w.wait()            # the current (compute) stream waits for the collective's stream; the host does not
         self._pending = []
 
     def _d_grads_consumed(self, bi: int) -> bool:
         """Discriminator gradients produced in batch `bi` are used by an optimiser step only if
         the next stepping batch (the first bs >= bi with (bs+1) % accum == 0, where both gradient
         sets are zeroed) is also a discriminator batch; otherwise they are zeroed unread, so the
-        step skips computing them.  Parameters, losses and BatchNorm buffers are unaffected."""
+        step skips computing them.  When the epoch ends before that batch the gradients carry over
+        into the next epoch, whose batch index restarts at 0 (src/train.py:176): the consuming step
+        is then batch accum - 1 of that epoch.  Parameters, losses and BatchNorm buffers are unaffected."""
+        if not self.use_gan:
+            return False
         bs = bi + (self.accum - 1 - bi % self.accum)
-        return self.use_gan and bs % self.d_update_interval == 0
+        if self.epoch_batches is not None and bs >= self.epoch_batches:
+            if self.epoch_batches < self.accum:
+                return True      # no stepping batch in sight: keep what the reference would keep
+            bs = self.accum - 1
+        return bs % self.d_update_interval == 0
 
     def _set_d_requires_grad(self, flag: bool):
         if self._d_req != flag:
@@ -201,7 +310,10 @@ class Trainer:
 
     # ---- one batch ------------------------------------------------------------------------
     def train_step(self, images, output_image, station_positions, station_runoffs) -> Dict[str, torch.Tensor]:
-        """One iteration of the reference's batch loop.  Returns loss tensors (no host sync)."""
+        """One iteration of the reference's batch loop (src/train.py:176-268).  Returns loss
+        tensors (no host sync).  The three Inf/NaN checks of src/train.py:193-199,221-222 set device
+        flags (read them with nan_report()); with mixed precision an optimiser step whose
+        gradients hold Inf/NaN is skipped on the device, as GradScaler.step does (src/train.py:255-260)."""
         bi = self.batch_idx
         self.model.train()
         stepping = (bi + 1) % self.accum == 0
@@ -212,19 +324,20 @@ class Trainer:
             self._set_d_requires_grad(d_live)
         images = images.to(self.device, non_blocking=True)
         output_image = output_image.to(self.device, non_blocking=True)
-        ops.nan_inf_flag(images.contiguous().float().view(-1), self.nan_flag)
+        ops.nan_inf_flag(images.contiguous().float().view(-1), self.nan_flags[_FLAG_IMAGES:_FLAG_IMAGES + 1])
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp):
             pred = self.model(images)
-            ops.nan_inf_flag(pred.view(-1), self.nan_flag)
+            ops.nan_inf_flag(pred.view(-1), self.nan_flags[_FLAG_PRED:_FLAG_PRED + 1])
             ld = self.loss_fn(pred, output_image, station_positions, station_runoffs)
             loss_g = ld["total"]
             if self.use_gan:
-                pred_fake = self.discriminator(pred)
+                pred_fake = self.discriminator(pred, keep_record=d_batch)
                 fake_record = self.discriminator.last_record
                 g_gan = self.gan_loss_fn.gan_loss(pred_fake, torch.ones(1, device=self.device))
                 loss_g = loss_g + self.gan_weight * g_gan
                 ld["gan_g"] = g_gan
                 ld["total"] = loss_g
+            ops.nan_inf_flag(loss_g.detach().reshape(1), self.nan_flags[_FLAG_LOSS:_FLAG_LOSS + 1])
         (loss_g / self.accum).backward()
         if d_batch:
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp), torch.set_grad_enabled(d_live):
@@ -242,16 +355,27 @@ class Trainer:
             if d_batch:
                 self.opt_d.gather()
             if self.distributed:
-                # big gradients are already on their way (hooks); everything else is one buffer
-                self._pending.append(dist.all_reduce(self.opt_g.gsmall, async_op=True))
+                # big gradients are already on their way (hooks); everything else is one buffer per
+                # network.  Every rank issues the same collectives in the same order for a given
+                # batch index.
+                self._all_reduce(self.opt_g.gsmall)
                 if d_batch:
-                    self._pending += [dist.all_reduce(self.opt_d.gsmall, async_op=True)]
-                    self._pending += [dist.all_reduce(p.grad, async_op=True) for p in self.opt_d.big if p.grad is not None]
+                    self._all_reduce(self.opt_d.gsmall)
+                    for p in self.opt_d.big:
+                        if p.grad is not None:
+                            self._all_reduce(p.grad)
                 self._wait_reduces()
                 scale = 1.0 / self.world
-            self.opt_g.step(scale)
+            found = None
+            if self.use_amp:
+                # after the exchange, so that every rank takes the same decision
+                found = self.found_inf
+                found.zero_()
+                for g in self.opt_g.grads() + (self.opt_d.grads() if d_batch else []):
+                    ops.nan_inf_flag(g, found)
+            self.opt_g.step(scale, found)
             if d_batch:
-                self.opt_d.step(scale)
+                self.opt_d.step(scale, found)
             self.opt_g.zero_grad()
             if self.use_gan:
                 self.opt_d.zero_grad()
@@ -259,6 +383,92 @@ class Trainer:
             self.discriminator.last_record = None
         self.batch_idx += 1
         return ld
+
+    # ---- epochs ---------------------------------------------------------------------------
+    def train_epoch(self, dataloader) -> Dict[str, float]:
+        """Trainer.train_epoch (src/train.py:154-305): one pass over `dataloader` (batches are
+        dicts with images, output_image, station_positions, stations), the batch index restarting
+        at 0; returns {'loss', 'image_loss', 'station_loss'} (means over the batches) and logs the
+        reference's running-mean line every log_interval batches.  The per-batch losses are summed
+        on the device; the host reads them only for a log line and at the end of the epoch."""
+        self.model.train()
+        self.batch_idx = 0
+        try:
+            self.epoch_batches = len(dataloader)
+        except TypeError:
+            self.epoch_batches = None
+        sums = torch.zeros(3, device=self.device, dtype=torch.float64)
+        num_batches = 0
+        for batch_idx, batch in enumerate(dataloader):
+            ld = self.train_step(batch["images"], batch["output_image"], batch["station_positions"], batch["stations"])
+            sums += torch.stack([ld["total"].detach().double().reshape(()), ld["image"].double().reshape(()),
+                                 ld["station"].double().reshape(())])
+            num_batches += 1
+            if (batch_idx + 1) % self.log_interval == 0:
+                s = (sums / num_batches).tolist()
+                msg = f"Epoch {self.epoch} Batch {batch_idx + 1}: Loss={s[0]:.6f}, Img={s[1]:.6f}, Stn={s[2]:.6f}"
+                if self.use_gan and "gan_d" in ld:
+                    msg += f", D_Loss={float(ld['gan_d'].detach()):.6f}"
+                self.logger.info(msg)
+                self._warn_nan()
+        self.epoch_batches = None
+        self._warn_nan()
+        if num_batches == 0:
+            raise ZeroDivisionError("train_epoch: the data loader produced no batch")
+        s = (sums / num_batches).tolist()
+        return {"loss": s[0], "image_loss": s[1], "station_loss": s[2]}
+
+    def _warn_nan(self):
+        """The reference's three warnings (src/train.py:193-199,221-222), emitted from the device
+        flags at the points where the host reads losses anyway."""
+        rep = self.nan_report()
+        for slot, text in _FLAG_WARNINGS.items():
+            if rep["flags"][slot]:
+                self.logger.warning(text)
+
+    def train(self, train_dataset, num_epochs: int = 100, val_dataset=None) -> None:
+        """Trainer.train (src/train.py:360-494): epochs of train_epoch (+ validate), the
+        reference's checkpoint files: best_model.pt on a validation improvement,
+        checkpoint_epoch_{e}.pt every 10th epoch, gan/gan_epoch_{e}.pt every epoch with GAN; all of
+        them the generator's bare state_dict."""
+        batch_size = self.config.get("train", {}).get("batch_size", 4)
+        output_dir = Path(self.config.get("data", {}).get("output_dir", "./output"))
+        output_dir.mkdir(parents=True, exist_ok=True)
+        self._attach_file_log(output_dir)
+        rank = dist.get_rank() if self.distributed else 0
+        for epoch in range(num_epochs):
+            self.epoch = epoch
+            train_metrics = self.train_epoch(_epoch_loader(train_dataset, batch_size, True, epoch, rank, self.world))
+            self.logger.info(f"Epoch {epoch} - Train Loss: {train_metrics['loss']:.6f}")
+            if val_dataset is not None:
+                val_metrics = self.validate(_epoch_loader(val_dataset, batch_size, False, epoch, 0, 1))
+                self.logger.info(f"Epoch {epoch} - Val Loss: {val_metrics['loss']:.6f}, "
+                                 f"RMSE: {val_metrics['RMSE']:.4f}, NSE: {val_metrics['NSE']:.4f}")
+                if val_metrics["loss"] < self.best_loss:
+                    self.best_loss = val_metrics["loss"]
+                    if rank == 0:
+                        self.save_model(str(output_dir / "best_model.pt"))
+                        self.logger.info(f"Model saved to {output_dir / 'best_model.pt'}")
+            if rank == 0 and (epoch + 1) % 10 == 0:
+                self.save_model(str(output_dir / f"checkpoint_epoch_{epoch}.pt"))
+                self.logger.info(f"Checkpoint saved to {output_dir / f'checkpoint_epoch_{epoch}.pt'}")
+            if rank == 0 and self.use_gan:
+                gan_dir = output_dir / "gan"
+                gan_dir.mkdir(parents=True, exist_ok=True)
+                self.save_model(str(gan_dir / f"gan_epoch_{epoch}.pt"))
+                self.logger.info(f"GAN Checkpoint saved to {gan_dir / f'gan_epoch_{epoch}.pt'}")
+        self.logger.info("Training complete!")
+
+    def _attach_file_log(self, log_dir: Path):
+        """training_<timestamp>.log in the output directory (src/train.py:113-131), one handler per
+        process however many Trainers are built."""
+        if any(getattr(h, "_sf_train_log", False) for h in self.logger.handlers):
+            return
+        self.logger.setLevel(logging.DEBUG if self.config.get("system", {}).get("debug", False) else logging.INFO)
+        h = logging.FileHandler(log_dir / f"training_{datetime.now().strftime('%Y%m%d_%H%M%S')}.log")
+        h.setFormatter(logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s"))
+        h._sf_train_log = True
+        self.logger.addHandler(h)
 
     def validate(self, batches) -> Dict[str, float]:
         """Trainer.validate (src/train.py:307-358): eval-mode forward over an iterable of batches
@@ -286,11 +496,20 @@ class Trainer:
         metrics["loss"] = float(total.item()) / max(n, 1)
         return metrics
 
+    def nan_report(self) -> Dict:
+        """Host-synchronising read (and reset) of the device flags: 'flags' = [input images,
+        predictions, loss, gradients] saw Inf/NaN since the last report (src/train.py:193,198,221;
+        the fourth is what GradScaler checks), 'skipped_steps' = optimiser steps skipped so far."""
+        vals = self.nan_flags.tolist()
+        self.nan_flags.zero_()
+        skipped = self.opt_g.skipped
+        if skipped:
+            vals[_FLAG_GRADS] = 1
+        return {"flags": [bool(v) for v in vals], "skipped_steps": skipped}
+
     def saw_nan_or_inf(self) -> bool:
-        """Host-synchronising read of the flag the three per-step checks of src/train.py:193,198,221 feed."""
-        bad = bool(self.nan_flag.item())
-        self.nan_flag.zero_()
-        return bad
+        """True when any of the checks fired since the last read (host-synchronising)."""
+        return any(self.nan_report()["flags"])
 
     def state_dict(self):
         return self.model.state_dict()
@@ -308,7 +527,7 @@ class Trainer:
         discriminator / accumulation schedule and the CPU generator state dropout seeds come from.
         Plain tensors, ints and strings only (loads with weights_only=True)."""
         ck = {"format": RESUME_FORMAT, "model": _host_state(self.model), "opt_g": self.opt_g.state_by_name(self.model),
-              "batch_idx": int(self.batch_idx), "cpu_rng_state": torch.get_rng_state()}
+              "batch_idx": int(self.batch_idx), "epoch": int(self.epoch), "cpu_rng_state": torch.get_rng_state()}
         if self.use_gan:
             ck["discriminator"] = _host_state(self.discriminator)
             ck["opt_d"] = self.opt_d.state_by_name(self.discriminator)
@@ -329,6 +548,7 @@ class Trainer:
             self.discriminator.load_state_dict(ck["discriminator"])
             self.opt_d.load_state_by_name(self.discriminator, ck["opt_d"])
         self.batch_idx = int(ck["batch_idx"])
+        self.epoch = int(ck.get("epoch", 0))
         torch.set_rng_state(ck["cpu_rng_state"])
         self.opt_g.zero_grad()
         if self.use_gan:
@@ -337,6 +557,45 @@ class Trainer:
 
 
 RESUME_FORMAT = "sfhip-resume-1"
+
+
+def _collate(batch):
+    """The collate function of src/train.py:379-390."""
+    return {"images": torch.stack([b["images"] for b in batch], dim=0),
+            "output_image": torch.stack([b["output_image"] for b in batch], dim=0),
+            "stations": [b["stations"] for b in batch],
+            "station_positions": [b["station_positions"] for b in batch]}
+
+
+class _ListLoader:
+    """A sized, re-iterable view of a batch generator (train_epoch asks for len())."""
+
+    def __init__(self, make, n):
+        self._make, self._n = make, n
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        return iter(self._make())
+
+
+def _epoch_loader(dataset, batch_size: int, shuffle: bool, epoch: int, rank: int, world: int):
+    """Batches of one epoch.  A dataset with a loader() method (ResidentStreamflowDataset) serves
+    them from HBM, sharded over the ranks; any other map-style dataset goes through
+    torch.utils.data.DataLoader with the reference's collate function (src/train.py:392-401)."""
+    if hasattr(dataset, "loader"):
+        n = len(dataset) // world
+        nb = (n + batch_size - 1) // batch_size
+        return _ListLoader(lambda: dataset.loader(batch_size, shuffle=shuffle, seed=0, epoch=epoch, rank=rank, world=world), nb)
+    from torch.utils.data import DataLoader
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=0)
+        sampler.set_epoch(epoch)
+    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler, num_workers=0,
+                      collate_fn=_collate)
 
 
 def _host_state(module: nn.Module) -> Dict[str, torch.Tensor]:

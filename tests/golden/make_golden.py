@@ -384,6 +384,57 @@ def gen_evaluate():
     save("evaluate", **out)
 
 
+def gen_evaluate_csv():
+    """The two CSV files Evaluator.evaluate_dataset writes (src/evaluate.py:294-333) for the run of
+    gen_evaluate: header and rows as text, plus the sample dates the rows carry."""
+    from generate_dummy_data import generate_dummy_data
+    from src.evaluate import Evaluator
+    import contextlib
+    import csv
+    import io
+    tmp = tempfile.mkdtemp(prefix="gold_evalcsv_")
+    np.random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        generate_dummy_data(days=9, stations=3, channels=2, height=64, width=64, output_dir=tmp)
+    cfg = model_cfg(16, "LSTM", 64, 2, k=3)
+    cfg["data"].update({"image_dir": os.path.join(tmp, "images"), "station_dir": os.path.join(tmp, "stations"),
+                        "output_dir": os.path.join(tmp, "output"), "region": [90, 150, -15, 25]})
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = StreamflowDataset(cfg["data"]["image_dir"], cfg["data"]["station_dir"], cfg, normalize=True)
+    m = StreamflowPredictionModel(cfg)
+    load_gold(m, "eval_g")
+    path = os.path.join(tmp, "model.pt")
+    torch.save(m.state_dict(), path)
+    outdir = os.path.join(tmp, "evalout")
+    Evaluator(cfg, path).evaluate_dataset(ds, outdir)
+    out = {"dates": np.array([str(ds[i]["date"]) for i in range(len(ds))])}
+    for name in ("stations_eval", "evaluation_metrics"):
+        with open(os.path.join(outdir, name + ".csv"), newline="") as f:
+            rows = list(csv.reader(f))
+        out[name + "_header"] = np.array(rows[0])
+        out[name + "_rows"] = np.array(rows[1:])
+    out["files"] = np.array(sorted(os.listdir(outdir)))
+    save("evaluate_csv", **out)
+
+
+def gen_disc_eval():
+    """PatchDiscriminator in eval mode (BatchNorm on its running statistics, src/model/gan.py:24-52)."""
+    out = {}
+    for size in (64, 50):
+        d = PatchDiscriminator(1, 16)
+        load_gold(d, "disc")
+        d.eval()
+        x = G.gold_tensor(f"disc/x{size}", (2, 1, size, size)).requires_grad_(True)
+        y = d(x)
+        gy = G.gold_tensor(f"disc/gy{size}", tuple(y.shape))
+        (y * gy).sum().backward()
+        out[f"y{size}"] = y
+        out[f"gx{size}"] = x.grad
+        out[f"g{size}_bn_w"] = d.model[3][1].weight.grad
+        out[f"g{size}_conv_w"] = d.model[3][0].weight.grad
+    save("discriminator_eval", **out)
+
+
 def dataset_case(tag):
     """Raw inputs of one dataset case (formula/seeded; written to disk for the reference to read)."""
     rs = np.random.RandomState({"A": 11, "B": 12}[tag])
@@ -520,9 +571,10 @@ def gen_baselines():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pixel", "encoder", "temporal", "decoder", "disc", "losses", "generator",
-                             "train", "evaluate", "dataset", "ckpt", "baselines"]
+                             "train", "evaluate", "dataset", "ckpt", "baselines", "evaluate_csv", "disc_eval"]
     fns = {"pixel": gen_pixel, "encoder": gen_encoder, "temporal": gen_temporal, "decoder": gen_decoder,
            "disc": gen_disc, "losses": gen_losses, "generator": gen_generator, "train": gen_train,
-           "evaluate": gen_evaluate, "dataset": gen_dataset, "ckpt": gen_ckpt, "baselines": gen_baselines}
+           "evaluate": gen_evaluate, "dataset": gen_dataset, "ckpt": gen_ckpt, "baselines": gen_baselines,
+           "evaluate_csv": gen_evaluate_csv, "disc_eval": gen_disc_eval}
     for w in which:
         fns[w]()

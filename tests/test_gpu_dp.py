@@ -1,5 +1,5 @@
 """Data-parallel train step on the GPU: two ranks (one process each, both on cuda:0, gloo
-carrying the device tensors) run training.Trainer.train_step with the exchange path the
+carrying the gradients through host memory) run training.Trainer.train_step with the exchange path the
 multi-GPU bench uses: big gradients all-reduced in place from post-accumulate hooks during
 backward, all other gradients in one flat buffer, the 1/world scale folded into the Adam launch.
 src/train.py has no data-parallel path; the properties checked are those of synchronous
@@ -50,18 +50,9 @@ def _worker(rank, world, port, same_data, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
+    # gloo is a host transport: the trainer stages the gradients through host memory for it
+    # (training.Trainer._all_reduce), exactly the calls, order and buffers the RCCL path uses
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # Test transport only: gloo stages device tensors through pinned host memory on a side stream,
-    # and with two processes sharing one GPU that path stalls unless the producing stream has
-    # drained (observed: the third step's first reduce never completes).  RCCL, which the real
-    # multi-GPU run uses, is stream ordered and needs no such sync.
-    real = dist.all_reduce
-
-    def synced_all_reduce(t, *args, **kw):
-        torch.cuda.synchronize()
-        return real(t, *args, **kw)
-
-    dist.all_reduce = synced_all_reduce
     try:
         sf = load_pkg()
         torch.manual_seed(1234 + rank)       # different random initialisation per rank
@@ -101,6 +92,40 @@ def test_two_ranks_on_the_same_data_match_one_process():
         pytest.skip("needs a GPU")
     (g0, d0, l0, _), (g1, d1, _, _) = _spawn(same_data=True)
     assert torch.equal(g0, g1) and torch.equal(d0, d1)
+    gs, ds, ls, _ = _run(load_pkg(), False, make_batches(2 * STEPS, 2, 3, 64)[:STEPS])
+    np.testing.assert_allclose(l0, ls, rtol=5e-4)
+    close(g0, gs.numpy(), 2e-3)
+    close(d0, ds.numpy(), 2e-3)
+
+
+def _rccl_worker(rank, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sf = load_pkg()
+        torch.manual_seed(1234)
+        out[0] = _run(sf, True, make_batches(2 * STEPS, 2, 3, 64)[:STEPS])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_exchange_path_with_one_rank_matches_the_plain_trainer():
+    """The code path the multi-GPU runs take -- RCCL process group, hooks issuing the big
+    all-reduces from the backward pass onto the communication stream, the flat-buffer reduces,
+    the stream waits -- with a world of one rank, where the sum over ranks is the identity: the
+    result must equal the trainer without any exchange."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
+    g0, d0, l0, _ = out[0]
+    torch.manual_seed(1234)
     gs, ds, ls, _ = _run(load_pkg(), False, make_batches(2 * STEPS, 2, 3, 64)[:STEPS])
     np.testing.assert_allclose(l0, ls, rtol=5e-4)
     close(g0, gs.numpy(), 2e-3)

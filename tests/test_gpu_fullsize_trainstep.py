@@ -56,14 +56,17 @@ def test_full_size_train_steps_against_oracle(mode):
     tr.model.temporal_module.dropout = 0.0
     ref = O.TrainerOracle(CFG, {k: v.clone() for k, v in g_sd.items()}, {k: v.clone() for k, v in d_sd.items()})
     keys = ("total", "image", "station", "gan_g", "gan_d")
-    for b in _batches(3):
+    for i, b in enumerate(_batches(3)):
         args = (b["images"], b["output_image"], b["station_positions"], b["stations"])
         o = tr.train_step(*args)
         w = ref.step(*args)
         assert set(k for k in keys if k in o) == set(k for k in keys if k in w)
+        # the first batch precedes every parameter update (forward + losses only): in f32 mode it is
+        # held to the forward tolerance, 1e-5
+        tol_i = 1e-5 if (i == 0 and mode == "f32") else tol
         for k in keys:
             if k in w:
-                assert abs(float(o[k].detach() if torch.is_tensor(o[k]) else o[k]) - w[k]) <= tol * max(abs(w[k]), 1e-3), (k, o[k], w[k])
+                assert abs(float(o[k].detach() if torch.is_tensor(o[k]) else o[k]) - w[k]) <= tol_i * max(abs(w[k]), 1e-3), (i, k, o[k], w[k])
     assert not tr.saw_nan_or_inf()
     for mod, sd in ((tr.model, ref.g_sd), (tr.discriminator, ref.d_sd)):
         for k, v in mod.state_dict().items():

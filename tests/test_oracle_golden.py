@@ -437,3 +437,22 @@ def test_baseline_models_restatement(name):
     close(y, g[f"{name}_train"], 1e-5)
     close(new["reducer.encoder.7.running_mean"], g[f"{name}_rm7"], 1e-5)
     close(new["reducer.encoder.1.running_var"], g[f"{name}_rv1"], 1e-5)
+
+
+@pytest.mark.parametrize("size", [64, 50])
+def test_discriminator_eval_mode(size):
+    """PatchDiscriminator.eval(): BatchNorm on its running statistics, no buffer updates
+    (golden from the reference's module in eval mode)."""
+    g = golden("discriminator_eval")
+    sd = gstate(disc_shapes(16), "disc")
+    for k in sd:
+        if sd[k].dtype.is_floating_point and "running" not in k:
+            sd[k].requires_grad_(True)
+    x = G.gold_tensor(f"disc/x{size}", (2, 1, size, size)).requires_grad_(True)
+    y, upd = O.discriminator_forward(x, sd, training=False)
+    assert not upd
+    close(y, g[f"y{size}"], 2e-5)
+    (y * G.gold_tensor(f"disc/gy{size}", tuple(y.shape))).sum().backward()
+    close_robust(x.grad, g[f"gx{size}"], 1e-4)
+    close(sd["model.3.1.weight"].grad, g[f"g{size}_bn_w"], 1e-3)
+    close(sd["model.3.0.weight"].grad, g[f"g{size}_conv_w"], 1e-3)
