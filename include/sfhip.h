@@ -102,6 +102,22 @@ int sf_conv3x3(const void* in, const void* wp, const float* bias, const void* au
                int aux_mode, int out_dtype, void* stream);
 
 /*
+ * 4x4 stride-2 pad-1 convolution, bf16 NHWC, forward or data gradient (the PatchGAN blocks,
+ * nn.Conv2d(k=4,s=2,p=1) at src/model/gan.py:24-34), on the same persistent LDS-DMA scheme: the
+ * filter splits into four 2x2 filters by pixel parity, each stage stages one parity plane's patch.
+ * dgrad = 0: in [N,IH,IW,C] -> out [N,OH,OW,ldo], OH = (IH-2)/2+1; wp packed [K][16][C] with tap
+ *   index (py*2+px)*4 + a*2+b holding filter position (2a+py, 2b+px).
+ * dgrad = 1: in = gradient of the conv output [N,IH,IW,C], out = gradient of the conv input
+ *   [N,OH,OW,ldo], IH = (OH-2)/2+1; wp packed transposed [K = conv input channels][16][C = conv
+ *   output channels], tap index (py*2+px)*4 + a*2+b holding filter position (3-py-2a, 3-px-2b).
+ * C % 16 == 0, K % 8 == 0, K <= 1024; bias f32 [K] or NULL; act / aux / aux_mode as in
+ * sf_gemm_desc (aux: bf16 tensor shaped like out).
+ */
+int sf_conv4x4s2(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N,
+                 int IH, int IW, int C, int OH, int OW, int K, int ldo, int dgrad, int act,
+                 int aux_mode, void* stream);
+
+/*
  * Convolution weight gradients, bf16 NHWC, f32 OIHW result (overwritten):
  *   sf_wgrad3x3:   3x3 stride 1 pad 1 (src/model/cnn_encoder.py:45-51, src/model/decoder.py:148-150)
  *                  dw[k][c][r*3+s] = sum_pixels dout[y][x][k] * x[y+r-1][x+s-1][c]

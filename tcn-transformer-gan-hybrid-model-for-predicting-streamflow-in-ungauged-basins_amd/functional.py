@@ -435,9 +435,13 @@ class DiscriminatorFn(torch.autograd.Function):
             oh, ow = (ih - 2) // 2 + 1, (iw - 2) // 2 + 1
             if oh < 1 or ow < 1:
                 raise ValueError("input too small for the PatchGAN discriminator")
-            wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(16)), False, K, C)
             z = torch.empty((N, oh, ow, K), device=x.device, dtype=cdtype)
-            ops.conv_fprop(y, wp, z, _s2_geom(N, ih, iw, C, oh, ow), K, bias=b.detach().contiguous())
+            if ops.conv4x4s2_ok(y, K, K):
+                wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, ops.s2_tap_order(False), False, K, C)
+                ops.conv4x4s2(y, wp, z, K, bias=b.detach().contiguous())
+            else:
+                wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(16)), False, K, C)
+                ops.conv_fprop(y, wp, z, _s2_geom(N, ih, iw, C, oh, ow), K, bias=b.detach().contiguous())
             M = N * oh * ow
             ws = None
             if training:
@@ -490,6 +494,12 @@ class DiscriminatorFn(torch.autograd.Function):
                 grads[2 + 6 * i + 2], grads[2 + 6 * i + 3] = dgamma, dbeta
             # data gradient: four parity classes of the transposed stride-2 conv
             dyin = torch.empty_like(yin)
+            if ops.conv4x4s2_ok(dz, C, C):
+                wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, ops.s2_tap_order(True), True, C, K)
+                # layer 0 sits on a conv without BatchNorm: fold its LeakyReLU derivative in
+                ops.conv4x4s2(dz, wT, dyin, C, dgrad=True, aux=yin if i == 0 else None, aux_mode=2 if i == 0 else 0)
+                dy = dyin
+                continue
             problems = []
             for (py, px, taps, rs, mh, mw) in _s2_dgrad_classes(ih, iw):
                 wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, rs, True, C, K)

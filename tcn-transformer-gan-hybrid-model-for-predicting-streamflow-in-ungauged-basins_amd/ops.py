@@ -65,7 +65,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv4x4s2", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
@@ -262,6 +262,46 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
         return
     geom = conv_geom(N, H, W, C, H, W, 1, 1, H, W, taps, tap_rs=list(range(9)))
     conv_fprop(x, wp, out, geom, K, bias=bias, act=act, aux=aux, aux_mode=aux_mode, tag=tag)
+
+
+def s2_tap_order(dgrad: bool) -> List[int]:
+    """Filter positions r*4+s in the order sf_conv4x4s2 expects its 16 packed taps: class
+    (py, px) = parity of the pixel read (forward) / written (data gradient), then (a, b)."""
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            for a in (0, 1):
+                for b in (0, 1):
+                    out.append((3 - py - 2 * a) * 4 + (3 - px - 2 * b) if dgrad else (2 * a + py) * 4 + (2 * b + px))
+    return out
+
+
+def conv4x4s2_ok(x: torch.Tensor, K: int, ldo: int) -> bool:
+    """bf16 NHWC with a multiple of 16 reduction channels and 8-channel output groups."""
+    return (x.dtype == torch.bfloat16 and x.shape[-1] % 16 == 0 and K % 8 == 0 and ldo % 8 == 0 and K <= 1024
+            and x.shape[1] * x.shape[2] * x.shape[3] * 2 < 2 ** 31 - 1 and not FORCE_GENERIC_CONV)
+
+
+def conv4x4s2(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0):
+    """4x4 stride-2 pad-1 conv (x = layer input) or its data gradient (x = gradient of the conv
+    output, out = gradient of the conv input); wp packed with s2_tap_order(dgrad)."""
+    _dev(x, wp, out, bias, aux, dtypes=[torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.float32, torch.bfloat16])
+    N, IH, IW, C = x.shape
+    No, OH, OW, ldo = out.shape
+    if No != N or tuple(wp.shape) != (K if not dgrad else wp.shape[0], 16, C) or wp.shape[0] < K:
+        raise RuntimeError("conv4x4s2: operand shapes do not match")
+    if aux is not None and aux.shape != out.shape:
+        raise RuntimeError("conv4x4s2: the mask operand must have the output's shape")
+    rec = TIMED.get("conv_s2_dgrad_kernel" if dgrad else "conv_s2_fwd_kernel")
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(lib().sf_conv4x4s2(_p(x), _p(wp), _p(bias), _p(aux), _p(out), N, IH, IW, C, OH, OW, K, ldo, int(dgrad), act,
+                              aux_mode, _stream()), "sf_conv4x4s2")
+    if rec is not None:
+        e1.record()
+        pix = N * (IH * IW if dgrad else OH * OW)
+        rec.append((e0, e1, 2.0 * pix * C * K * 16))
 
 
 def wgrad3x3(x, dout, dw, tag=None):
