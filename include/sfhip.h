@@ -96,15 +96,22 @@ int sf_gemm_batch(int n, const sf_gemm_desc* d, const void* const* A, const void
  * in [N,H,W,C] (C % 16 == 0); wp packed [K][9][C]; tap t reads the input at offset
  * (dy[t], dx[t]) in [-1,1]^2 (host arrays of 9 ints); out NHWC [N,H,W,ldo] (out_dtype);
  * bias f32 [K] or NULL; act / aux / aux_mode as in sf_gemm_desc.
+ * w_staged != 0: wp is the output of sf_conv3x3_stage_weights (the per-stage LDS images of the
+ * weights, so that every 1 KiB copy piece reads contiguous memory); only shapes for which
+ * sf_conv3x3_staged_weight_bytes(C, K) > 0 take it.
  */
 int sf_conv3x3(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N,
                int H, int W, int C, int K, int ldo, const int* dy, const int* dx, int act,
-               int aux_mode, int out_dtype, void* stream);
+               int aux_mode, int out_dtype, int w_staged, void* stream);
+size_t sf_conv3x3_staged_weight_bytes(int C, int K);
+int sf_conv3x3_stage_weights(const void* wp, void* out, int C, int K, void* stream);
 
 /*
  * 4x4 stride-2 pad-1 convolution, bf16 NHWC, forward or data gradient (the PatchGAN blocks,
  * nn.Conv2d(k=4,s=2,p=1) at src/model/gan.py:24-34), on the same persistent LDS-DMA scheme: the
  * filter splits into four 2x2 filters by pixel parity, each stage stages one parity plane's patch.
+ * The weights go in as the stages' LDS images (so that every 1 KiB copy piece reads contiguous
+ * memory): ws = sf_conv4x4s2_stage_weights(wp) of sf_conv4x4s2_staged_weight_bytes(C, K) bytes, from
  * dgrad = 0: in [N,IH,IW,C] -> out [N,OH,OW,ldo], OH = (IH-2)/2+1; wp packed [K][16][C] with tap
  *   index (py*2+px)*4 + a*2+b holding filter position (2a+py, 2b+px).
  * dgrad = 1: in = gradient of the conv output [N,IH,IW,C], out = gradient of the conv input
@@ -113,7 +120,9 @@ int sf_conv3x3(const void* in, const void* wp, const float* bias, const void* au
  * C % 16 == 0, K % 8 == 0, K <= 1024; bias f32 [K] or NULL; act / aux / aux_mode as in
  * sf_gemm_desc (aux: bf16 tensor shaped like out).
  */
-int sf_conv4x4s2(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N,
+size_t sf_conv4x4s2_staged_weight_bytes(int C, int K);
+int sf_conv4x4s2_stage_weights(const void* wp, void* ws, int C, int K, void* stream);
+int sf_conv4x4s2(const void* in, const void* ws, const float* bias, const void* aux, void* out, int N,
                  int IH, int IW, int C, int OH, int OW, int K, int ldo, int dgrad, int act,
                  int aux_mode, void* stream);
 

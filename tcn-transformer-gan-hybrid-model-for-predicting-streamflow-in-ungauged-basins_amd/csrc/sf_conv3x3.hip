@@ -28,6 +28,7 @@ struct C3Params {
     int TH, TW, tiles_x, tiles_y, ktiles;
     int act, aux_mode, out_dtype;
     int dy[9], dx[9];
+    int wstaged;
 };
 
 __device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
@@ -260,6 +261,7 @@ struct C3DParams {
     int TH, TW, tiles_x, tiles_y, ntiles, ktiles, nchunks;
     int act, aux_mode, out_dtype;
     int dy[9], dx[9];
+    int wstaged;     // weights given as the stages' LDS images (sf_conv3x3_stage_weights): contiguous 1 KiB copy pieces
 };
 
 struct ItemPos {
@@ -309,6 +311,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         w_k[i] = k;
         w_rel[i] = ((k * 9 + t) * p.C + (wch << 3)) * 2;          // bytes
         if ((wch << 3) >= p.C) w_rel[i] = -1;                    // C < 32: beyond the tensor -> zeros
+        if (p.wstaged) w_rel[i] = (wave + 8 * i) * 1024 + lane * 16;   // the image itself, in copy order
     }
     int p_rel[D_NPJ], p_pyx[D_NPJ];
 #pragma unroll
@@ -333,9 +336,10 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // and touch no memory, and the MFMA loop needs no branch around them.
     auto stage_src = [&](const ItemPos& it, bool live) {
         const int c0 = it.chunk * CK;
-        const bf16* wbase = p.w + (size_t)it.k0 * 9 * p.C + c0;
+        const bf16* wbase = p.wstaged ? p.w + ((size_t)(it.k0 / KT) * p.nchunks + it.chunk) * (D_WIMG / 2)
+                                      : p.w + (size_t)it.k0 * 9 * p.C + c0;
         const bf16* ibase = p.in + (size_t)it.n * p.H * p.W * p.C + c0;
-        const unsigned wbytes = live ? (unsigned)(((p.K - it.k0) * 9 * p.C - c0) * 2) : 0u;
+        const unsigned wbytes = !live ? 0u : p.wstaged ? (unsigned)D_WIMG : (unsigned)(((p.K - it.k0) * 9 * p.C - c0) * 2);
         const unsigned ibytes = live ? (unsigned)((p.H * p.W * p.C - c0) * 2) : 0u;
         StageSrc ss;
         ss.wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wbytes, 0x00020000);
@@ -642,7 +646,7 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
     C3DParams p;
     p.in = q.in; p.w = q.w; p.bias = q.bias; p.aux = q.aux; p.out = q.out;
     p.N = q.N; p.H = q.H; p.W = q.W; p.C = q.C; p.K = q.K; p.ldo = q.ldo;
-    p.act = q.act; p.aux_mode = q.aux_mode; p.out_dtype = q.out_dtype;
+    p.act = q.act; p.aux_mode = q.aux_mode; p.out_dtype = q.out_dtype; p.wstaged = q.wstaged;
     for (int t = 0; t < 9; ++t) { p.dy[t] = q.dy[t]; p.dx[t] = q.dx[t]; }
     pick_tile_dma(p.H, p.W, &p.TH, &p.TW);
     p.tiles_x = (p.W + p.TW - 1) / p.TW;
@@ -709,11 +713,54 @@ template <int KT, int CK> int launch3(const C3Params& p, hipStream_t s) {
     return SF_OK;
 }
 
+// [K][9][C] packed weights -> the LDS images of the wide shape's stages, one 36,864-byte block per
+// (128-channel output tile, 16-channel input chunk): rows t * 128 + k of 32 bytes, the 16-byte slot
+// already XORed with (row >> 3) & 1, zeros beyond K and C.
+__global__ void stage_weights_kernel(const bf16* __restrict__ wp, bf16* __restrict__ out, int K, int C, int nchunks,
+                                     long long total) {
+    using Cf = DCfg<128, 16>;
+    constexpr int PER = Cf::WIMG / 2;     // elements per stage image
+    for (long long o = blockIdx.x * 256LL + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int stage = (int)(o / PER), within = (int)(o % PER);
+        const int row = within / 16, e = within % 16;
+        const int ch = (((e >> 3) ^ Cf::swz(row)) << 3) + (e & 7);
+        const int t = row / 128, k = (stage / nchunks) * 128 + row % 128, c = (stage % nchunks) * 16 + ch;
+        out[o] = (k < K && c < C) ? wp[((size_t)k * 9 + t) * C + c] : (bf16)0.f;
+    }
+}
+
+// the shape sf_conv3x3 runs a problem on: 0 = wide <128,16>, 1 = resident <64,32>, 2 = <64,32>, 3 / 4 = register-staged
+int conv3_variant(int C, int K) {
+    if (K <= D_BIAS_MAX && C % 16 == 0 && (K > 64 || C % 32 != 0)) return 0;
+    if (K <= 64 && C == 64) return 1;
+    if (K <= D_BIAS_MAX && C % 32 == 0) return 2;
+    if (K <= 64 && C % 32 == 0) return 3;
+    return 4;
+}
+
 }  // namespace
+
+extern "C" size_t sf_conv3x3_staged_weight_bytes(int C, int K) {
+    if (C <= 0 || K <= 0 || C % 16 || conv3_variant(C, K) != 0) return 0;
+    return (size_t)((K + 127) / 128) * ((C + 15) / 16) * DCfg<128, 16>::WIMG;
+}
+
+extern "C" int sf_conv3x3_stage_weights(const void* wp, void* out, int C, int K, void* stream) {
+    SF_REQUIRE(wp && out, "sf_conv3x3_stage_weights: null argument");
+    const size_t bytes = sf_conv3x3_staged_weight_bytes(C, K);
+    SF_REQUIRE(bytes > 0, "sf_conv3x3_stage_weights: the %d -> %d channel conv does not run on the staged-weight kernel", C, K);
+    const long long total = (long long)(bytes / 2);
+    long long grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(stage_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)wp,
+                       (bf16*)out, K, C, (C + 15) / 16, total);
+    SF_LAUNCH_CHECK("sf_conv3x3_stage_weights");
+    return SF_OK;
+}
 
 extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N, int H,
                           int W, int C, int K, int ldo, const int* dy, const int* dx, int act, int aux_mode,
-                          int out_dtype, void* stream) {
+                          int out_dtype, int w_staged, void* stream) {
     SF_REQUIRE(in && wp && out && dy && dx, "sf_conv3x3: null argument");
     SF_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "sf_conv3x3: bad shape");
     SF_REQUIRE(C % 16 == 0, "sf_conv3x3: C=%d must be a multiple of 16", C);
@@ -724,7 +771,8 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
     C3Params p;
     p.in = (const bf16*)in; p.w = (const bf16*)wp; p.bias = bias; p.aux = (const bf16*)aux; p.out = out;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.ldo = ldo;
-    p.act = act; p.aux_mode = aux_mode; p.out_dtype = out_dtype;
+    p.act = act; p.aux_mode = aux_mode; p.out_dtype = out_dtype; p.wstaged = w_staged ? 1 : 0;
+    SF_REQUIRE(!w_staged || conv3_variant(C, K) == 0, "sf_conv3x3: staged weights given for a shape that does not take them");
     for (int t = 0; t < 9; ++t) {
         SF_REQUIRE(dy[t] >= -1 && dy[t] <= 1 && dx[t] >= -1 && dx[t] <= 1, "sf_conv3x3: tap offsets must lie in [-1, 1]");
         p.dy[t] = dy[t]; p.dx[t] = dx[t];
@@ -733,13 +781,11 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
     p.tiles_x = (W + p.TW - 1) / p.TW;
     p.tiles_y = (H + p.TH - 1) / p.TH;
     hipStream_t s = (hipStream_t)stream;
-    if (K <= D_BIAS_MAX && C % 16 == 0 && (K > 64 || C % 32 != 0)) return launch3_dma<128, 16>(p, s);
-    if (K <= 64 && C == 64) return launch3_dma<64, 32, true>(p, s);   // both weight stages resident in LDS
-    if (K <= D_BIAS_MAX && C % 32 == 0) return launch3_dma<64, 32>(p, s);
-    if (K <= 64 && C % 32 == 0) {
-        p.ktiles = (K + 63) / 64;
-        return launch3<64, 32>(p, s);
+    switch (conv3_variant(C, K)) {
+        case 0: return launch3_dma<128, 16>(p, s);
+        case 1: return launch3_dma<64, 32, true>(p, s);   // both weight stages resident in LDS
+        case 2: return launch3_dma<64, 32>(p, s);
+        case 3: p.ktiles = (K + 63) / 64; return launch3<64, 32>(p, s);
+        default: p.ktiles = (K + 127) / 128; return launch3<128, 16>(p, s);
     }
-    p.ktiles = (K + 127) / 128;
-    return launch3<128, 16>(p, s);
 }

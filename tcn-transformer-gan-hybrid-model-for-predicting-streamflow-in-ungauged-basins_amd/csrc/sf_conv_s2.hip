@@ -39,7 +39,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct S2Params {
     const bf16* in;        // forward: layer input [N,IH,IW,C]; data gradient: output gradient [N,IH,IW,C]
-    const bf16* w;         // packed [K][16][C], tap index class * 4 + a * 2 + b
+    const bf16* w;         // staged weight images, one per (128-channel output tile, class, 16-channel chunk)
     const float* bias;
     const bf16* aux;
     bf16* out;             // [N,OH,OW,ldo]
@@ -84,14 +84,11 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     // ---- DMA jobs (tile-invariant part): a job fills RPP consecutive 32-byte rows; lane l writes slot
     // l % 2 of row l / 2 and fetches the channel chunk slot ^ swz(row)
     const int jrow = lane / SLOTS, jslot = lane % SLOTS;
+    // the weights arrive as the stages' LDS images (sf_conv4x4s2_stage_weights): every copy piece
+    // reads 1 KiB of contiguous memory
     int w_rel[NWJ];
 #pragma unroll
-    for (int i = 0; i < NWJ; ++i) {
-        const int row = RPP * (wave + 8 * i) + jrow;         // t * KT + k
-        const int t = row / KT, k = row % KT;
-        const int wch = jslot ^ swz(row);
-        w_rel[i] = ((k * WTOT + t) * p.C + (wch << 3)) * 2;   // bytes
-    }
+    for (int i = 0; i < NWJ; ++i) w_rel[i] = (wave + 8 * i) * 1024 + lane * 16;   // bytes
     int p_rel[NPJ], p_pyx[NPJ];
 #pragma unroll
     for (int i = 0; i < NPJ; ++i) {
@@ -112,10 +109,9 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
         const int cls = DGRAD ? it.cls : it.chunk / p.cch;
         const int c0 = (DGRAD ? it.chunk : it.chunk - cls * p.cch) * CK;
         const int py = cls >> 1, px = cls & 1;
-        const int woff = (cls * 4) * p.C + c0;               // inside the first weight row of the block
-        const bf16* wbase = p.w + (size_t)it.k0 * WTOT * p.C + woff;
+        const bf16* wbase = p.w + ((size_t)((it.k0 / KT) * 4 + cls) * p.cch + c0 / CK) * (WIMG / 2);
         const bf16* ibase = p.in + (size_t)it.n * p.IH * p.IW * p.C + c0;
-        const unsigned wbytes = live ? (unsigned)(((p.K - it.k0) * WTOT * p.C - woff) * 2) : 0u;
+        const unsigned wbytes = live ? (unsigned)WIMG : 0u;
         const unsigned ibytes = live ? (unsigned)((p.IH * p.IW * p.C - c0) * 2) : 0u;
         StageSrc ss;
         ss.wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wbytes, 0x00020000);
@@ -354,7 +350,41 @@ void pick_tile_s2(int H, int W, int* th, int* tw) {
     *th = bth; *tw = btw;
 }
 
+// packed [K][16][C] weights (tap index class * 4 + a * 2 + b) -> the LDS images of the stages, one
+// 16,384-byte block per (128-channel output tile, class, 16-channel chunk): rows (a*2+b) * 128 + k
+// of 32 bytes, the 16-byte slot already XORed with (row >> 3) & 1, zeros beyond K
+__global__ void stage_weights_s2_kernel(const bf16* __restrict__ wp, bf16* __restrict__ out, int K, int C, int cch,
+                                        long long total) {
+    constexpr int PER = WIMG / 2;
+    for (long long o = blockIdx.x * 256LL + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int stage = (int)(o / PER), within = (int)(o % PER);
+        const int row = within / CK, e = within % CK;
+        const int ch = (((e >> 3) ^ swz(row)) << 3) + (e & 7);
+        const int chunk = stage % cch, cls = (stage / cch) & 3, kt = stage / (4 * cch);
+        const int t = row / KT, k = kt * KT + row % KT, c = chunk * CK + ch;
+        out[o] = k < K ? wp[((size_t)k * WTOT + cls * 4 + t) * C + c] : (bf16)0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" size_t sf_conv4x4s2_staged_weight_bytes(int C, int K) {
+    if (C <= 0 || K <= 0 || C % CK) return 0;
+    return (size_t)((K + KT - 1) / KT) * 4 * (C / CK) * WIMG;
+}
+
+extern "C" int sf_conv4x4s2_stage_weights(const void* wp, void* out, int C, int K, void* stream) {
+    SF_REQUIRE(wp && out, "sf_conv4x4s2_stage_weights: null argument");
+    const size_t bytes = sf_conv4x4s2_staged_weight_bytes(C, K);
+    SF_REQUIRE(bytes > 0, "sf_conv4x4s2_stage_weights: %d reduction channels, must be a positive multiple of 16", C);
+    const long long total = (long long)(bytes / 2);
+    long long grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(stage_weights_s2_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)wp,
+                       (bf16*)out, K, C, C / CK, total);
+    SF_LAUNCH_CHECK("sf_conv4x4s2_stage_weights");
+    return SF_OK;
+}
 
 extern "C" int sf_conv4x4s2(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N,
                             int IH, int IW, int C, int OH, int OW, int K, int ldo, int dgrad, int act, int aux_mode,
@@ -375,8 +405,7 @@ extern "C" int sf_conv4x4s2(const void* in, const void* wp, const float* bias, c
         SF_REQUIRE(OH == (IH - 2) / 2 + 1 && OW == (IW - 2) / 2 + 1, "sf_conv4x4s2: output %dx%d does not belong to a %dx%d input", OH,
                    OW, IH, IW);
     }
-    SF_REQUIRE(2LL * IH * IW * C < 0x7fffffffLL && 2LL * K * WTOT * C < 0x7fffffffLL,
-               "sf_conv4x4s2: one image or the weights exceed 2 GiB");
+    SF_REQUIRE(2LL * IH * IW * C < 0x7fffffffLL, "sf_conv4x4s2: one image exceeds 2 GiB");
     S2Params p;
     p.in = (const bf16*)in; p.w = (const bf16*)wp; p.bias = bias; p.aux = (const bf16*)aux; p.out = (bf16*)out;
     p.N = N; p.IH = IH; p.IW = IW; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.ldo = ldo;

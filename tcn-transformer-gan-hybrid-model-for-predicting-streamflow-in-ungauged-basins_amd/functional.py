@@ -87,7 +87,7 @@ class EncoderFn(torch.autograd.Function):
                 h, w = h // 2, w // 2
                 continue
             z = torch.empty((N, h, w, Kpad), device=x.device, dtype=cdtype)
-            ops.conv3x3(a, wp, z, Kpad, flop_c=wt.shape[1], flop_k=K)
+            ops.conv3x3(a, ops.conv3x3_stage_weights(wp, C, Kpad), z, Kpad, flop_c=wt.shape[1], flop_k=K)
             ws = None
             if training:
                 ws = ops.bn_ws(Kpad, x.device)
@@ -134,7 +134,7 @@ class EncoderFn(torch.autograd.Function):
             if l > 0 or ctx.needs_input_grad[0]:
                 wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), True, C, Kpad)
                 da = torch.empty((N, h, w, C), device=dz.device, dtype=cdtype)
-                ops.conv3x3(dz, wT, da, C, dgrad=True, flop_c=K, flop_k=cin_real)
+                ops.conv3x3(dz, ops.conv3x3_stage_weights(wT, Kpad, C), da, C, dgrad=True, flop_c=K, flop_k=cin_real)
                 if l > 0:
                     dy = da
                 else:
@@ -437,8 +437,7 @@ class DiscriminatorFn(torch.autograd.Function):
                 raise ValueError("input too small for the PatchGAN discriminator")
             z = torch.empty((N, oh, ow, K), device=x.device, dtype=cdtype)
             if ops.conv4x4s2_ok(y, K, K):
-                wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, ops.s2_tap_order(False), False, K, C)
-                ops.conv4x4s2(y, wp, z, K, bias=b.detach().contiguous())
+                ops.conv4x4s2(y, ops.conv4x4s2_weights(wt, False), z, K, bias=b.detach().contiguous())
             else:
                 wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(16)), False, K, C)
                 ops.conv_fprop(y, wp, z, _s2_geom(N, ih, iw, C, oh, ow), K, bias=b.detach().contiguous())
@@ -495,9 +494,9 @@ class DiscriminatorFn(torch.autograd.Function):
             # data gradient: four parity classes of the transposed stride-2 conv
             dyin = torch.empty_like(yin)
             if ops.conv4x4s2_ok(dz, C, C):
-                wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, ops.s2_tap_order(True), True, C, K)
                 # layer 0 sits on a conv without BatchNorm: fold its LeakyReLU derivative in
-                ops.conv4x4s2(dz, wT, dyin, C, dgrad=True, aux=yin if i == 0 else None, aux_mode=2 if i == 0 else 0)
+                ops.conv4x4s2(dz, ops.conv4x4s2_weights(wt, True), dyin, C, dgrad=True, aux=yin if i == 0 else None,
+                              aux_mode=2 if i == 0 else 0)
                 dy = dyin
                 continue
             problems = []

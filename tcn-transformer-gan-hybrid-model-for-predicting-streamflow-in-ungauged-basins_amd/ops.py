@@ -56,6 +56,8 @@ def lib():
         L.sf_transformer_save_floats.restype = ctypes.c_size_t
         L.sf_lstm_save_floats.restype = ctypes.c_size_t
         L.sf_wgrad3x3_workspace_bytes.restype = ctypes.c_size_t
+        L.sf_conv3x3_staged_weight_bytes.restype = ctypes.c_size_t
+        L.sf_conv4x4s2_staged_weight_bytes.restype = ctypes.c_size_t
         L.sf_wgrad4x4s2_workspace_bytes.restype = ctypes.c_size_t
         L.sf_enc1_bwd_workspace_bytes.restype = ctypes.c_size_t
         L.sf_date_image_metrics_workspace_bytes.restype = ctypes.c_size_t
@@ -65,7 +67,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv4x4s2", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
@@ -252,8 +254,9 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
             e0.record()
         dy = (_c_int * 9)(*[t[0] for t in taps])
         dx = (_c_int * 9)(*[t[1] for t in taps])
+        staged = getattr(wp, "_sf_staged", False)
         _check(lib().sf_conv3x3(_p(x), _p(wp), _p(bias), _p(aux), _p(out), N, H, W, C, K, out.shape[-1], dy, dx, act,
-                                aux_mode, code_of(out.dtype), _stream()), "sf_conv3x3")
+                                aux_mode, code_of(out.dtype), int(staged), _stream()), "sf_conv3x3")
         if rec is not None:
             e1.record()
             # algorithmic flops: real (unpadded) channel counts when the caller states them
@@ -282,13 +285,26 @@ def conv4x4s2_ok(x: torch.Tensor, K: int, ldo: int) -> bool:
             and x.shape[1] * x.shape[2] * x.shape[3] * 2 < 2 ** 31 - 1 and not FORCE_GENERIC_CONV)
 
 
-def conv4x4s2(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0):
+def conv4x4s2_weights(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    """f32 OIHW 4x4 weights -> the staged bf16 operand of conv4x4s2 (forward or data gradient)."""
+    O, I = w.shape[0], w.shape[1]
+    rows, cols = (I, O) if dgrad else (O, I)
+    wp = pack_conv_weight(w.detach().contiguous(), torch.bfloat16, s2_tap_order(dgrad), dgrad, rows, cols)
+    nbytes = int(lib().sf_conv4x4s2_staged_weight_bytes(cols, rows))
+    if nbytes == 0:
+        raise RuntimeError("conv4x4s2_weights: the reduction channel count must be a multiple of 16")
+    ws = torch.empty(nbytes // 2, device=w.device, dtype=torch.bfloat16)
+    _check(lib().sf_conv4x4s2_stage_weights(_p(wp), _p(ws), cols, rows, _stream()), "sf_conv4x4s2_stage_weights")
+    return ws
+
+
+def conv4x4s2(x, ws, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0):
     """4x4 stride-2 pad-1 conv (x = layer input) or its data gradient (x = gradient of the conv
-    output, out = gradient of the conv input); wp packed with s2_tap_order(dgrad)."""
-    _dev(x, wp, out, bias, aux, dtypes=[torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.float32, torch.bfloat16])
+    output, out = gradient of the conv input); ws from conv4x4s2_weights(w, dgrad)."""
+    _dev(x, ws, out, bias, aux, dtypes=[torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.float32, torch.bfloat16])
     N, IH, IW, C = x.shape
     No, OH, OW, ldo = out.shape
-    if No != N or tuple(wp.shape) != (K if not dgrad else wp.shape[0], 16, C) or wp.shape[0] < K:
+    if No != N or ws.numel() * 2 != int(lib().sf_conv4x4s2_staged_weight_bytes(C, K)):
         raise RuntimeError("conv4x4s2: operand shapes do not match")
     if aux is not None and aux.shape != out.shape:
         raise RuntimeError("conv4x4s2: the mask operand must have the output's shape")
@@ -296,12 +312,31 @@ def conv4x4s2(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, 
     if rec is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _check(lib().sf_conv4x4s2(_p(x), _p(wp), _p(bias), _p(aux), _p(out), N, IH, IW, C, OH, OW, K, ldo, int(dgrad), act,
+    _check(lib().sf_conv4x4s2(_p(x), _p(ws), _p(bias), _p(aux), _p(out), N, IH, IW, C, OH, OW, K, ldo, int(dgrad), act,
                               aux_mode, _stream()), "sf_conv4x4s2")
     if rec is not None:
         e1.record()
         pix = N * (IH * IW if dgrad else OH * OW)
         rec.append((e0, e1, 2.0 * pix * C * K * 16))
+
+
+def conv3x3_stage_weights(wp: torch.Tensor, C: int, K: int) -> torch.Tensor:
+    """Packed [K][9][C] bf16 weights -> the staged form sf_conv3x3 copies in contiguous pieces, when
+    the shape runs on the kernel that takes it; otherwise wp itself.  The result carries a marker
+    that conv3x3 reads."""
+    if wp.dtype != torch.bfloat16 or FORCE_GENERIC_CONV or not STAGE_CONV_WEIGHTS:
+        return wp
+    nbytes = int(lib().sf_conv3x3_staged_weight_bytes(C, K))
+    if nbytes == 0:
+        return wp
+    _dev(wp)
+    out = torch.empty(nbytes // 2, device=wp.device, dtype=torch.bfloat16)
+    _check(lib().sf_conv3x3_stage_weights(_p(wp), _p(out), C, K, _stream()), "sf_conv3x3_stage_weights")
+    out._sf_staged = True
+    return out
+
+
+STAGE_CONV_WEIGHTS = os.environ.get("SF_STAGE_CONV_WEIGHTS", "1") != "0"   # debug switch for A/B timing
 
 
 def wgrad3x3(x, dout, dw, tag=None):

@@ -38,7 +38,7 @@ def test_forward_and_data_gradient_small(sf, shape):
     OH, OW = (IH - 2) // 2 + 1, (IW - 2) // 2 + 1
     x, w, b = _operands(N, IH, IW, C, K, seed=sum(shape))
     xd = x.to(DEV)
-    wp = ops.pack_conv_weight(w.to(DEV).contiguous(), torch.bfloat16, ops.s2_tap_order(False), False, K, C)
+    wp = ops.conv4x4s2_weights(w.to(DEV), False)
     z = torch.full((N, OH, OW, K), float("nan"), device=DEV, dtype=torch.bfloat16)
     assert ops.conv4x4s2_ok(xd, K, K)
     ops.conv4x4s2(xd, wp, z, K, bias=b.to(DEV))
@@ -49,7 +49,7 @@ def test_forward_and_data_gradient_small(sf, shape):
     # data gradient, with and without the LeakyReLU mask operand
     g = torch.Generator().manual_seed(7)
     dz = torch.randn(N, OH, OW, K, generator=g).to(torch.bfloat16)
-    wT = ops.pack_conv_weight(w.to(DEV).contiguous(), torch.bfloat16, ops.s2_tap_order(True), True, C, K)
+    wT = ops.conv4x4s2_weights(w.to(DEV), True)
     dref = F.conv_transpose2d(dz.float().permute(0, 3, 1, 2), w, stride=2, padding=1,
                               output_padding=(IH - ((OH - 1) * 2 + 2), IW - ((OW - 1) * 2 + 2)))
     assert dref.shape[-2:] == (IH, IW)
@@ -73,7 +73,7 @@ def test_full_size_layers_against_generic_path_and_f32(sf, layer):
     x = torch.randn(N, IH, IH, C, device=DEV).to(torch.bfloat16)
     w = (torch.randn(K, C, 4, 4, device=DEV) / (4.0 * C ** 0.5)).to(torch.bfloat16).float()
     b = torch.randn(K, device=DEV)
-    wp = ops.pack_conv_weight(w.contiguous(), torch.bfloat16, ops.s2_tap_order(False), False, K, C)
+    wp = ops.conv4x4s2_weights(w, False)
     z = torch.empty(N, OH, OH, K, device=DEV, dtype=torch.bfloat16)
     ops.conv4x4s2(x, wp, z, K, bias=b)
     wg = ops.pack_conv_weight(w.contiguous(), torch.bfloat16, list(range(16)), False, K, C)
@@ -84,7 +84,7 @@ def test_full_size_layers_against_generic_path_and_f32(sf, layer):
         f32 = F.conv2d(x[i:i + 1].float().permute(0, 3, 1, 2).cpu(), w.cpu(), b.cpu(), stride=2, padding=1)
         close(z[i:i + 1].float().permute(0, 3, 1, 2), f32.numpy(), 6e-3)
     dz = torch.randn(N, OH, OH, K, device=DEV).to(torch.bfloat16)
-    wT = ops.pack_conv_weight(w.contiguous(), torch.bfloat16, ops.s2_tap_order(True), True, C, K)
+    wT = ops.conv4x4s2_weights(w, True)
     dx = torch.empty(N, IH, IH, C, device=DEV, dtype=torch.bfloat16)
     ops.conv4x4s2(dz, wT, dx, C, dgrad=True)
     for i in (0, N - 1):

@@ -36,8 +36,8 @@ for (IH, C, K) in ((200, 64, 128), (100, 128, 256), (50, 256, 512)):
     dx = torch.empty_like(x)
     dw = torch.empty(K, C, 4, 4, device=DEV)
     fl = 2.0 * N * OH * OH * C * K * 16
-    wp = ops.pack_conv_weight(w, torch.bfloat16, ops.s2_tap_order(False), False, K, C)
-    wT = ops.pack_conv_weight(w, torch.bfloat16, ops.s2_tap_order(True), True, C, K)
+    wp = ops.conv4x4s2_weights(w, False)
+    wT = ops.conv4x4s2_weights(w, True)
     wg = ops.pack_conv_weight(w, torch.bfloat16, list(range(16)), False, K, C)
     geom = fn._s2_geom(N, IH, IH, C, OH, OH)
     t_new = timeit(lambda: ops.conv4x4s2(x, wp, z, K, bias=b))
