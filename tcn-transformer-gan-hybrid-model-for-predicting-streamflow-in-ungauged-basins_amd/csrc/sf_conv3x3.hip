@@ -33,6 +33,20 @@ struct C3Params {
 
 __device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
 
+#ifdef SF_CONV3_STAMPS
+// diagnostic build only (tools/conv_stamps.py): shader-clock stamps of wave 0 of every workgroup
+// around the barrier, the stage and the epilogue of its first STAMP_STEPS pipeline steps
+constexpr int STAMP_STEPS = 48;
+__device__ unsigned long long g_stamps[256 * STAMP_STEPS * 4];
+#define SF_STAMP(slot)                                                                              \
+    do {                                                                                            \
+        if (tid == 0 && stamp_step < STAMP_STEPS)                                                   \
+            g_stamps[(blockIdx.x * STAMP_STEPS + stamp_step) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SF_STAMP(slot) do { } while (0)
+#endif
+
 template <int KT, int CK>
 __global__ __launch_bounds__(NT3, 2) void conv3x3_kernel(C3Params p) {
     constexpr int LD = CK + 8;                 // padded row (elements): conflict-free b128 reads
@@ -416,9 +430,13 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         const char* wl0 = wts + aLane0;
         const char* wl1 = wts + aLane1;
         const char* pl = cur + P_OFF;
-        bf16x8 fa[2][MT], fb[2][2];
+        // fragment ring: the reads of position i + PF are issued before the MFMAs of position i (PF = 2
+        // where a position holds only four MFMAs per wave, the resident-weight shape: one position
+        // ahead does not cover the LDS latency there)
+        constexpr int PF = RES ? 2 : 1, RING = PF + 1;
+        bf16x8 fa[RING][MT], fb[RING][2];
         auto issue = [&](int i) {
-            const int t = i / KS, ks = i % KS, s = i & 1;
+            const int t = i / KS, ks = i % KS, s = i % RING;
 #pragma unroll
             for (int a = 0; a < MT; ++a)
                 fa[s][a] = *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (t * KT + a * 32) * ROWB);
@@ -426,18 +444,27 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
             for (int c = 0; c < 2; ++c)
                 fb[s][c] = *reinterpret_cast<const bf16x8*>(pl + (pa[c][t] ^ (ks << 5)));
         };
-        static_assert(D_NWJ + D_NPJ <= NPOS, "one copy piece per position");
-        issue(0);
+        // copy pieces of the next stage issued per tap position: all of them early in the stage, so
+        // that the last one has most of the stage to land before the barrier waits for it
+#ifndef SF_CONV3_PPP
+#define SF_CONV3_PPP 3
+#endif
+        constexpr int PPP = SF_CONV3_PPP;
+        static_assert(D_NWJ + D_NPJ <= NPOS * PPP, "copy pieces per position");
+#pragma unroll
+        for (int i = 0; i < PF; ++i) issue(i);
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
-            if (i + 1 < NPOS) issue(i + 1);
-            if (i < D_NWJ + D_NPJ) issue_piece(ss, fill, i);
+            if (i + PF < NPOS) issue(i + PF);
+#pragma unroll
+            for (int j = i * PPP; j < (i + 1) * PPP; ++j)
+                if (j < D_NWJ + D_NPJ) issue_piece(ss, fill, j);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][a], fb[i & 1][c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % RING][a], fb[i % RING][c], acc[a][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -445,7 +472,12 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // Epilogue of an item.  The ReLU-mask loads are issued together and without branches; the
     // bias comes from LDS (copied there once per workgroup).
     const float* sbias = reinterpret_cast<const float*>(smd + 2 * D_BUF);
-    auto epilogue = [&](const ItemPos& it) {
+    // RES with 64 output channels: a pixel's output row is exactly one 128-byte line.  `lines` (a
+    // 4 KB slice per wave of the patch buffer the item's last stage was computed from) then takes the
+    // 16-byte pieces of 32 pixels, and the wave stores them back out as whole lines, 8 lanes per
+    // pixel, with streaming (non-temporal) stores: the output then neither leaves partial lines for L2
+    // to merge nor pushes the input lines of the next stages out of it.
+    auto epilogue = [&](const ItemPos& it, char* lines) {
         long long pixoff[2];
         bool pv[2];
 #pragma unroll
@@ -539,7 +571,12 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                         const auto s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
                         const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
-                        if (pv[c] && k < p.K)
+                        if (RES && lines) {
+                            // row r of the wave's slice, 16-byte slot (channel group) XOR (r >> 1) & 7
+                            const int G = a * 4 + 2 * gp + h;
+                            *reinterpret_cast<uint4*>(lines + wave * 4096 + r * 128 + ((G ^ ((r >> 1) & 7)) << 4)) =
+                                make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        } else if (pv[c] && k < p.K)
                             *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.out) + pixoff[c] + k) =
                                 make_uint4(s0[0], s1[0], s0[1], s1[1]);
                     } else {
@@ -561,6 +598,27 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                         }
                     }
                 }
+            if (RES && lines && wide_out) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int G = lane & 7;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pr = (lane >> 3) + 8 * j;                   // pixel row of the slice
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(lines + wave * 4096 + pr * 128 + ((G ^ ((pr >> 1) & 7)) << 4));
+                    const int q = wave * 64 + c * 32 + pr;
+                    const int ly = q / p.TW, lx = q - ly * p.TW;
+                    const int gy = it.y0 + ly, gx = it.x0 + lx;
+                    if (q < TP && gy < p.H && gx < p.W)
+                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.out) +
+                                                    (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo + G * 8));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                          // the slice is rewritten for the next 32 pixels
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
     };
 
@@ -569,6 +627,12 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         float* sb = reinterpret_cast<float*>(smd + 2 * D_BUF);
         for (int i = tid; i < D_BIAS_MAX; i += D_NT) sb[i] = i < p.K ? p.bias[i] : 0.f;
     }
+    // whole-line streaming stores: bf16 output rows of exactly 64 channels (one 128-byte line each)
+    const bool line_stores = RES && p.K == 64 && p.ldo == 64 && p.out_dtype == SF_BF16 &&
+                             (reinterpret_cast<uintptr_t>(p.out) & 127) == 0;
+#ifdef SF_CONV3_STAMPS
+    int stamp_step = 0;
+#endif
     ItemPos cur, nxt;
     cur.q = jblk; cur.chunk = 0;
     if (cur.q >= nitems) return;
@@ -600,8 +664,14 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
         const StageSrc ss = stage_src(nxt, nxt.q < nitems);
         run_stage(cur_buf, fill, ss, RES ? smd + cur.chunk * D_WIMG : cur_buf);
+        SF_STAMP(2);
         if (cur.chunk == p.nchunks - 1) {
-            epilogue(cur);
+            char* lines = nullptr;
+            if (RES && line_stores) {
+                __syncthreads();          // every wave is done reading the patch the pieces are parked in
+                lines = const_cast<char*>(cur_buf);
+            }
+            epilogue(cur, lines);
             zero_acc();
         }
         cur = nxt;
@@ -610,14 +680,32 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     while (true) {
         // the stage's copy has landed (own vmcnt, then the barrier) and every wave is done
         // reading the buffer the next copy goes to
+        SF_STAMP(0);
         __syncthreads();
+        SF_STAMP(1);
         step(buf0, buf1);
+        SF_STAMP(3);
+#ifdef SF_CONV3_STAMPS
+        ++stamp_step;
+#endif
         if (cur.q >= nitems) break;
+        SF_STAMP(0);
         __syncthreads();
+        SF_STAMP(1);
         step(buf1, buf0);
+        SF_STAMP(3);
+#ifdef SF_CONV3_STAMPS
+        ++stamp_step;
+#endif
         if (cur.q >= nitems) break;
     }
 }
+
+#ifdef SF_CONV3_STAMPS
+extern "C" int sf_conv3x3_read_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // (plain kernels around the templated body: hipcc does not emit the host stub of a kernel
 // template whose body holds these buffer-resource lambdas)

@@ -14,7 +14,8 @@ from typing import List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfhip.so")
+# SF_LIB: another build of the same library (diagnostic / A-B timing builds under tools/diag)
+LIB_PATH = os.environ.get("SF_LIB") or os.path.join(_HERE, "libsfhip.so")
 
 F32, BF16 = 0, 1
 OUT_NHWC, OUT_JI, OUT_IJ, OUT_OIHW = 0, 1, 2, 3
