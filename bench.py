@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--exchange-rehearsal", action="store_true",
                     help="N=1 only: run the data-parallel gradient exchange (RCCL process group of one rank, hooks, "
                          "flat-buffer all-reduce) that N>1 uses, to rehearse that code on a one-GPU box")
+    ap.add_argument("--static-wgrad", action="store_true",
+                    help="distributed / rehearsal runs: keep the weight-gradient kernel's fixed tile slices")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +113,8 @@ def main():
     ops = sf.ops
 
     cfg = bench_config(a.batch)
+    if a.static_wgrad:
+        cfg["system"]["dp_dynamic_wgrad"] = False
     torch.manual_seed(0)
     region = cfg["data"]["region"]
 

@@ -126,6 +126,15 @@ int sf_conv4x4s2(const void* in, const void* ws, const float* bias, const void* 
                  int IH, int IW, int C, int OH, int OW, int K, int ldo, int dgrad, int act,
                  int aux_mode, void* stream);
 
+/* Process-wide knob of sf_wgrad3x3.  dynamic = 0 (default): every workgroup streams a fixed slice
+ * of the tiles and the result is bit-reproducible.  dynamic = 1: the slice is only the workgroup's
+ * own list; a workgroup that has finished its list takes tiles from the lists of the others, so
+ * that a workgroup which starts late or shares its CU with another kernel (RCCL's, in data-parallel
+ * training) gets help instead of stretching the launch; when that happens the partition of the sums
+ * differs from the fixed one (last-bit differences).  dynamic = 2: as 1, and every second workgroup
+ * leaves its whole list to the others (a self-test of the stealing, for the test-suite).  No
+ * counterpart in the reference (it has no data-parallel path). */
+int sf_set_wgrad_scheduling(int dynamic);
 /*
  * Convolution weight gradients, bf16 NHWC, f32 OIHW result (overwritten):
  *   sf_wgrad3x3:   3x3 stride 1 pad 1 (src/model/cnn_encoder.py:45-51, src/model/decoder.py:148-150)

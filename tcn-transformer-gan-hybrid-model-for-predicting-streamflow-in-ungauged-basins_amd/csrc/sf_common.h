@@ -141,3 +141,29 @@ __device__ __forceinline__ AxisW axis_w(int dst, int in, int out) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Work queues of the persistent kernels.  A launch owns one slot of a small pool of counter sets
+// (a file-scope __device__ array of the kernel's translation unit, zero at load): heads[] are
+// bumped by workgroups asking for their next item, `done` counts workgroups that have left; the
+// last one to leave zeroes the slot again, so nothing has to be cleared between launches.  The
+// host hands out slots round-robin: a slot is reused only after SF_QUEUE_SLOTS - 1 later launches
+// of that kernel family, by which time stream order has long retired its earlier user.
+#define SF_QUEUE_SLOTS 64
+#define SF_QUEUE_HEADS 124
+struct WorkQueue {
+    int heads[SF_QUEUE_HEADS];
+    int done;
+    int pad[3];
+};
+// next item of list `h` beyond the `first` items that were dealt out statically (one lane calls this)
+__device__ __forceinline__ int queue_take(WorkQueue* q, int h) {
+    return __hip_atomic_fetch_add(&q->heads[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// called once per workgroup by one lane, after the value of its last queue_take has arrived
+__device__ __forceinline__ void queue_leave(WorkQueue* q, int nheads, int nworkgroups) {
+    const int old = __hip_atomic_fetch_add(&q->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nworkgroups - 1) {       // everyone else has left (and taken its last item) already
+        for (int i = 0; i < nheads; ++i) __hip_atomic_store(&q->heads[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}

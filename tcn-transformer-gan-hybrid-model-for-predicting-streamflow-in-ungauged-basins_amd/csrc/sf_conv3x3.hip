@@ -12,6 +12,7 @@
 // burst).  D is kept as [kout][pixel] so a lane stores 4 consecutive channels per access.
 #include "sf_common.h"
 #include "../../include/sfhip.h"
+#include <atomic>
 
 namespace {
 
@@ -32,6 +33,9 @@ struct C3Params {
 };
 
 __device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
+
+__device__ WorkQueue g_queues[SF_QUEUE_SLOTS];
+std::atomic<unsigned> g_launches{0};     // hands out the queue slots of this file's kernels, round-robin
 
 #ifdef SF_CONV3_STAMPS
 // diagnostic build only (tools/conv_stamps.py): shader-clock stamps of wave 0 of every workgroup
@@ -276,6 +280,7 @@ struct C3DParams {
     int act, aux_mode, out_dtype;
     int dy[9], dx[9];
     int wstaged;     // weights given as the stages' LDS images (sf_conv3x3_stage_weights): contiguous 1 KiB copy pieces
+    int qslot;       // work-queue slot of this launch, -1: items dealt statically
 };
 
 struct ItemPos {
@@ -298,10 +303,18 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     const int r = lane & 31, h = lane >> 5;
     const int PW = p.TW + 2, PP = (p.TH + 2) * PW, TP = p.TH * p.TW;
 
-    // ---- work list of this workgroup
+    // ---- work list of this workgroup: the items of "its" XCD (tiles xcd, xcd + 8, ...  times the
+    // output-channel blocks).  Every workgroup starts on item jblk; the following ones are taken
+    // from the XCD's queue head as the workgroup gets there, so a workgroup that starts late or runs
+    // slowly (a CU shared with a communication kernel) simply takes fewer items.
     const int xcd = blockIdx.x & 7, jblk = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
     const int xtiles = xcd < p.ntiles ? (p.ntiles - xcd + 7) >> 3 : 0;
     const int nitems = xtiles * p.ktiles;
+    __shared__ int s_next[2];
+    const bool dyn = p.qslot >= 0 && p.nchunks >= 2;
+    WorkQueue* const wq = g_queues + (p.qslot >= 0 ? p.qslot : 0);
+    int q_par = 0, q_pending = 0;
+    bool q_have = false;
     auto decode = [&](ItemPos& it) {
         const int m = it.q / p.ktiles, kt = it.q - m * p.ktiles;
         const int tile = xcd + 8 * m;
@@ -635,7 +648,10 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
 #endif
     ItemPos cur, nxt;
     cur.q = jblk; cur.chunk = 0;
-    if (cur.q >= nitems) return;
+    if (cur.q >= nitems) {
+        if (p.qslot >= 0 && tid == 0) queue_leave(wq, 8, gridDim.x);
+        return;
+    }
     decode(cur);
     char* const buf0 = RES ? smd + 2 * D_WIMG : smd;
     char* const buf1 = buf0 + (RES ? Cf::PIMG : D_BUF);
@@ -652,10 +668,19 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         for (int j = 0; j < D_NWJ + D_NPJ; ++j) issue_piece(ss, buf0, j);
     }
     nxt = cur;
+    if (dyn && tid == 0) s_next[0] = nb8 + queue_take(wq, xcd);     // read after the first barrier at the earliest
     auto advance = [&](ItemPos& it) {
         if (++it.chunk == p.nchunks) {
             it.chunk = 0;
-            it.q += nb8;
+            if (dyn) {
+                // the item taken a whole item ago; lane 0 asks for the one after it now and parks
+                // the answer in the other slot after the next barrier (it has arrived by then)
+                it.q = __builtin_amdgcn_readfirstlane(s_next[q_par]);
+                q_par ^= 1;
+                if (tid == 0) { q_pending = nb8 + queue_take(wq, xcd); q_have = true; }
+            } else {
+                it.q += nb8;
+            }
             if (it.q < nitems) decode(it);
         }
     };
@@ -677,12 +702,16 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         cur = nxt;
         advance(nxt);
     };
+    auto park = [&]() {
+        if (dyn && tid == 0 && q_have) { s_next[q_par] = q_pending; q_have = false; }
+    };
     while (true) {
         // the stage's copy has landed (own vmcnt, then the barrier) and every wave is done
         // reading the buffer the next copy goes to
         SF_STAMP(0);
         __syncthreads();
         SF_STAMP(1);
+        park();
         step(buf0, buf1);
         SF_STAMP(3);
 #ifdef SF_CONV3_STAMPS
@@ -692,12 +721,18 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         SF_STAMP(0);
         __syncthreads();
         SF_STAMP(1);
+        park();
         step(buf1, buf0);
         SF_STAMP(3);
 #ifdef SF_CONV3_STAMPS
         ++stamp_step;
 #endif
         if (cur.q >= nitems) break;
+    }
+    if (p.qslot >= 0 && tid == 0) {
+        // q_pending is read here so that the last take has returned before the workgroup counts as gone
+        if (q_have && q_pending < 0) return;
+        queue_leave(wq, 8, gridDim.x);
     }
 }
 
@@ -762,6 +797,7 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
     long long items = ntiles * p.ktiles;
     long long grid = (items + 7) / 8 * 8;
     if (grid > 256) grid = 256;
+    p.qslot = items > grid ? (int)(g_launches.fetch_add(1) % SF_QUEUE_SLOTS) : -1;    // one item each: nothing to deal
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
     SF_LAUNCH_CHECK("sf_conv3x3");
     return SF_OK;

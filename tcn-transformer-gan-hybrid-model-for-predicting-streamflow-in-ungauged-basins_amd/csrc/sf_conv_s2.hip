@@ -20,6 +20,7 @@
 // on the ds_read_b128 side (conflict-free 16-lane read groups, as in the 3x3 kernel's wide shape).
 #include "sf_common.h"
 #include "../../include/sfhip.h"
+#include <atomic>
 
 namespace {
 
@@ -35,6 +36,9 @@ static_assert(WJOBS % 8 == 0, "every wave copies the same number of weight piece
 
 __device__ __forceinline__ int swz(int row) { return (row >> 3) & 1; }
 
+__device__ WorkQueue g_queues[SF_QUEUE_SLOTS];
+std::atomic<unsigned> g_launches{0};     // hands out the queue slots of this file's kernels, round-robin
+
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct S2Params {
@@ -47,6 +51,7 @@ struct S2Params {
     int GH, GW;            // pixel grid that is tiled (forward: OH x OW; gradient: one parity class of it)
     int TH, TW, tiles_x, tiles_y, ntiles, ktiles, cch;
     int act, aux_mode;
+    int qslot;             // work-queue slot of this launch, -1: items dealt statically
 };
 
 struct ItemPos {
@@ -68,6 +73,13 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     const int xcd = blockIdx.x & 7, jblk = blockIdx.x >> 3, nb8 = gridDim.x >> 3;
     const int xt = xcd < p.ntiles ? (p.ntiles - xcd + 7) >> 3 : 0;
     const int nitems = (DGRAD ? 4 * xt : xt) * p.ktiles;
+    // every workgroup starts on item jblk of its XCD's list and takes the following ones from the
+    // list's queue head as it gets there (a workgroup that starts late or runs slowly takes fewer)
+    __shared__ int s_next[2];
+    const bool dyn = p.qslot >= 0 && nchunks >= 2;
+    WorkQueue* const wq = g_queues + (p.qslot >= 0 ? p.qslot : 0);
+    int q_par = 0, q_pending = 0;
+    bool q_have = false;
     auto decode = [&](ItemPos& it) {
         int m = it.q / p.ktiles;
         const int kt = it.q - m * p.ktiles;
@@ -291,7 +303,10 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     }
     ItemPos cur, nxt;
     cur.q = jblk; cur.chunk = 0;
-    if (cur.q >= nitems) return;
+    if (cur.q >= nitems) {
+        if (p.qslot >= 0 && tid == 0) queue_leave(wq, 8, gridDim.x);
+        return;
+    }
     decode(cur);
     char* const buf0 = smd;
     char* const buf1 = smd + BUF;
@@ -301,14 +316,26 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
         for (int j = 0; j < NPIECE; ++j) issue_piece(ss, buf0, j);
     }
     nxt = cur;
+    if (dyn && tid == 0) s_next[0] = nb8 + queue_take(wq, xcd);     // read after the first barrier at the earliest
     auto advance = [&](ItemPos& it) {
         if (++it.chunk == nchunks) {
             it.chunk = 0;
-            it.q += nb8;
+            if (dyn) {
+                // the item taken a whole item ago; lane 0 asks for the one after it now and parks
+                // the answer in the other slot after the next barrier (it has arrived by then)
+                it.q = __builtin_amdgcn_readfirstlane(s_next[q_par]);
+                q_par ^= 1;
+                if (tid == 0) { q_pending = nb8 + queue_take(wq, xcd); q_have = true; }
+            } else {
+                it.q += nb8;
+            }
             if (it.q < nitems) decode(it);
         }
     };
     advance(nxt);
+    auto park = [&]() {
+        if (dyn && tid == 0 && q_have) { s_next[q_par] = q_pending; q_have = false; }
+    };
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
         const StageSrc ss = stage_src(nxt, nxt.q < nitems);
         run_stage(cur_buf, fill, ss);
@@ -323,11 +350,18 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
         // the stage's copy has landed (own vmcnt, then the barrier) and every wave is done reading the
         // buffer the next copy goes to
         __syncthreads();
+        park();
         step(buf0, buf1);
         if (cur.q >= nitems) break;
         __syncthreads();
+        park();
         step(buf1, buf0);
         if (cur.q >= nitems) break;
+    }
+    if (p.qslot >= 0 && tid == 0) {
+        // q_pending is read here so that the last take has returned before the workgroup counts as gone
+        if (q_have && q_pending < 0) return;
+        queue_leave(wq, 8, gridDim.x);
     }
 }
 
@@ -435,6 +469,7 @@ extern "C" int sf_conv4x4s2(const void* in, const void* wp, const float* bias, c
     const long long items = ntiles * p.ktiles * (dgrad ? 4 : 1);
     long long grid = (items + 7) / 8 * 8;
     if (grid > 256) grid = 256;
+    p.qslot = items > grid ? (int)(g_launches.fetch_add(1) % SF_QUEUE_SLOTS) : -1;    // one item each: nothing to deal
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(S_NT), lds, (hipStream_t)stream, p);
     SF_LAUNCH_CHECK("sf_conv4x4s2");
     return SF_OK;

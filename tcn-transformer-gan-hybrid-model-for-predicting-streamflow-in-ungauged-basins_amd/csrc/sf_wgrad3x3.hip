@@ -19,6 +19,7 @@
 //   4x4: waves = (k half, c half) x (taps 0-7 / 8-15), 8 accumulator tiles each.
 #include "sf_common.h"
 #include "../../include/sfhip.h"
+#include <atomic>
 
 namespace {
 
@@ -37,7 +38,26 @@ struct WPParams {
     int N, IH, IW, OH, OW, Kd, Cx;
     int TH, TW, tiles_x, tiles_y, ntiles, tiles_per_slice;
     int kt_tiles, ct_tiles, K64, C64, nslices;
+    int qslot;      // slot of the list counters when tiles can be stolen, -1: fixed slices
+    int shirk;      // self-test of the stealing: odd workers leave their whole list to the others
 };
+
+// Tile scheduling of wgrad3_dma_kernel.  0 (default): every workgroup streams a fixed slice of the
+// tiles: the slab sums are bit-reproducible.  1: the slice is only the workgroup's own list; a
+// workgroup that has finished its list takes tiles from the lists of the others (same XCD, same
+// weight block), so a workgroup that starts late or shares its CU with another kernel (RCCL's, in
+// data-parallel training) gets help instead of stretching the launch to twice its time.  Undisturbed,
+// nobody steals and the partition is the fixed one; otherwise the partition of the sum varies from
+// launch to launch (last-bit differences).
+std::atomic<int> g_dynamic_tiles{0};
+constexpr int STEAL_WORKERS = 512;      // workgroups of one launch at most
+struct StealQueue {
+    int next[STEAL_WORKERS];            // per workgroup: the next untaken position of its list
+    int done;                           // workgroups that have left
+    int pad[3];
+};
+__device__ StealQueue g_wqueues[SF_QUEUE_SLOTS];    // zero between launches: the last workgroup to leave resets its slot
+std::atomic<unsigned> g_wlaunches{0};
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_tr_p;
 
@@ -226,6 +246,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> struct IntC { static constexpr int value = N; };
 
+template <bool STEAL>
 __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
     extern __shared__ __attribute__((aligned(16))) char smw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
     // The copies are buffer loads with an LDS destination; the buffer is the tile's image, lane
     // offsets are 32-bit bytes, and an offset past the buffer's end writes zeros (padding,
     // pixels outside the tile, channels beyond the tensor).
-    auto issue_tile = [&](int tile, char* lbase) {
+    auto issue_tile = [&](int tile, char* lbase) __attribute__((always_inline)) {
         const int txi = tile % p.tiles_x;
         const int rest = tile / p.tiles_x;
         const int tyi = rest % p.tiles_y;
@@ -305,6 +326,8 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
             const int gy = iy0 + py, gx = ix0 + px;
             const bool ok = x_pyx[i] >= 0 && x_col_ok && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW;
             const int voff = ok ? xoff + x_rel[i] : (int)0x80000000;
+            // patch rows 368 .. 383 lie beyond the patch when tiles can be stolen, and carry the four words of the hand-over
+            if (STEAL && i == NXJ - 1 && jg0 == 3) continue;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(lbase + lds_x0 + i * 4096), 16, voff, 0, 0, 0);
         }
     };
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
     // Software pipeline over the flattened (step, tap) sequence: the transposed reads of position
     // i + 2 are issued before the MFMA of position i, in exactly this order, so every MFMA waits
     // only for its own operands (a counted lgkmcnt) while later reads stay in flight.
-    auto run_steps = [&](auto ntc, const char* aLane, const char* bBase) {
+    auto run_steps = [&](auto ntc, const char* aLane, const char* bBase) __attribute__((always_inline)) {
         constexpr int NT = decltype(ntc)::value;
         constexpr int TOT = G_NSTEPS * NT, DEPTH = 2;
         bf16x8 fa[2], fb[DEPTH + 1];
@@ -376,23 +399,124 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
     // One tile: start the DMA of the next tile into `fill`, run the MFMAs on `cur`.  The two
     // buffers are handed over as restrict pointers so that the compiler knows the reads of
     // `cur` cannot touch the DMA's destination (otherwise it drains the DMA before every read).
-    auto tile_body = [&](const char* __restrict__ cur, char* __restrict__ fill, int next_tile) {
+    auto tile_body = [&](const char* __restrict__ cur, char* __restrict__ fill, bool compute, int next_tile) __attribute__((always_inline)) {
         if (next_tile < p.ntiles) issue_tile(next_tile, fill);
-        if (wave_idle) return;  // this wave's 32 x 32 block lies entirely in the channel padding
+        if (wave_idle || !compute) return;  // this wave's 32 x 32 block lies entirely in the channel padding
         if (grp == 0) run_steps(IntC<5>{}, cur + aOff, cur + bOff);
         else run_steps(IntC<4>{}, cur + aOff, cur + bOff);
     };
 
-    const int tile_step = p.nslices;
-    if (slice < p.ntiles) issue_tile(slice, smw);
-    for (int tile = slice; tile < p.ntiles; tile += 2 * tile_step) {
-        // the tile's DMA has landed (each wave waits for its own, then the barrier) and every wave
-        // is done reading the other buffer
+    if constexpr (!STEAL) {
+        const int tile_step = p.nslices;
+        if (slice < p.ntiles) issue_tile(slice, smw);
+        for (int tile = slice; tile < p.ntiles; tile += 2 * tile_step) {
+            // the tile's DMA has landed (each wave waits for its own, then the barrier) and every wave
+            // is done reading the other buffer
+            __syncthreads();
+            tile_body(smw, smw + G_BUF, true, tile + tile_step);
+            if (tile + tile_step >= p.ntiles) break;
+            __syncthreads();
+            tile_body(smw + G_BUF, smw, true, tile + 2 * tile_step);
+        }
+    } else {
+        // Every workgroup owns the list of tiles its fixed slice would stream (position m of worker w:
+        // tile x + 8 w + nslices m) and draws positions from the list's counter; when its own list is
+        // used up, it draws from the lists of the other workers of its XCD and weight block that have
+        // positions left.  Wave 0 does the drawing, four tiles ahead of the MFMAs so that nobody waits
+        // for an answer: the ticket for t(i+4) is asked for while tile t(i) is computed, turned into
+        // a tile index and parked in LDS after the next barrier, read into a register by all waves an
+        // iteration later and used for the copy that starts an iteration after that.  The four words
+        // of LDS lie in the last 16 patch rows of buffer 0, which no copy touches (the host turns
+        // stealing on only when the patch leaves them free).  A position past the end of a list is a
+        // HOLE (an iteration without work); DONE says that no list had anything left.
+        constexpr int HOLE = 0x7ffffffe, DONE = 0x7fffffff;
+        StealQueue* const wq = g_wqueues + p.qslot;
+        const int x8 = blockIdx.x & 7, s8 = p.nslices >> 3, me = (blockIdx.x >> 3) / pairs;
+        int* const s_next = reinterpret_cast<int*>(smw + 2 * G_DIMG + 23 * 1024);     // slot of t(j): j % 3; t(0): 3
+        auto counter = [&](int w) { return &wq->next[x8 + 8 * (w * pairs + pair)]; };
+        auto tile_at = [&](int w, int m) {
+            const long long t = x8 + 8 * w + (long long)m * p.nslices;
+            return t < p.ntiles ? (int)t : HOLE;
+        };
+        // wave 0 only (all of it wave-uniform, `ticket` valid in lane 0)
+        bool stealing = false, have = false;
+        int from = me, ticket = 0;
+        auto take = [&]() {
+            from = me;
+            if (stealing) {     // a worker with positions left, the nearest after this one
+                from = -1;
+                int c = 0x7fffffff, len = 0;
+                if (lane < s8) {
+                    c = __hip_atomic_load(counter(lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int first = x8 + 8 * lane;
+                    len = first < p.ntiles ? (p.ntiles - first + p.nslices - 1) / p.nslices : 0;
+                }
+                const unsigned long long left = __ballot(c < len);
+                if (left) {
+                    const int sh = (me + 1) & 63;
+                    const unsigned long long rot = sh ? (left >> sh) | (left << (64 - sh)) : left;
+                    from = (__builtin_ctzll(rot) + sh) & 63;
+                }
+            }
+            // the ticket stays untouched until it is parked, so lane 0 does not wait for it here
+            if (from >= 0 && lane == 0)
+                ticket = __hip_atomic_fetch_add(counter(from), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have = true;
+        };
+        auto resolve = [&]() {      // the tile of the outstanding ticket
+            have = false;
+            if (from < 0) return DONE;
+            const int t = tile_at(from, __builtin_amdgcn_readfirstlane(ticket));
+            if (t == HOLE && from == me) stealing = true;
+            return t;
+        };
+        if (wave == 0) {
+            int base = 0;
+            if (p.shirk && (me & 1)) base = 0x100000;
+            else if (lane == 0) base = __hip_atomic_fetch_add(counter(me), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int t3 = tile_at(me, base + 3);
+            stealing = t3 == HOLE;
+            if (lane == 0) {
+                s_next[3] = tile_at(me, base);
+                s_next[1] = tile_at(me, base + 1);
+                s_next[2] = tile_at(me, base + 2);
+                s_next[0] = t3;
+            }
+        }
         __syncthreads();
-        tile_body(smw, smw + G_BUF, tile + tile_step);
-        if (tile + tile_step >= p.ntiles) break;
-        __syncthreads();
-        tile_body(smw + G_BUF, smw, tile + 2 * tile_step);
+        int cur_tile = __builtin_amdgcn_readfirstlane(s_next[3]);         // t(0)
+        int next_tile = __builtin_amdgcn_readfirstlane(s_next[1]);        // t(1)
+        if (cur_tile < p.ntiles) issue_tile(cur_tile, smw);
+        auto stage = [&](int it, const char* __restrict__ cur, char* __restrict__ fill) __attribute__((always_inline)) {
+            __syncthreads();
+            if (next_tile < p.ntiles) issue_tile(next_tile, fill);        // first of all: the copy needs the time
+            if (wave == 0 && have) {
+                const int t = resolve();                                   // t(it + 3)
+                if (lane == 0) s_next[it % 3] = t;
+            }
+            const int after_next = __builtin_amdgcn_readfirstlane(s_next[(it + 2) % 3]);   // t(it + 2)
+            if (wave == 0) take();                                         // t(it + 4)
+            tile_body(cur, fill, cur_tile < p.ntiles, DONE);
+            cur_tile = next_tile;
+            next_tile = after_next;
+        };
+        for (int it = 0; cur_tile != DONE; it += 2) {
+            stage(it, smw, smw + G_BUF);
+            if (cur_tile == DONE) break;
+            stage(it + 1, smw + G_BUF, smw);
+        }
+        if (wave == 0) {
+            if (have) asm volatile("" ::"v"(ticket));     // the last answer has arrived before the workgroup leaves
+            int last = 0;
+            if (lane == 0)
+                last = __hip_atomic_fetch_add(&wq->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+            if (__builtin_amdgcn_readfirstlane(last)) {     // everyone else has left: the slot is ready for its next launch
+                for (int i = lane; i < (int)gridDim.x; i += 64)
+                    __hip_atomic_store(&wq->next[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(&wq->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 
     // ---- slab store: ws[slice][k][t][c]; rows = kout (registers), column = lane
@@ -421,8 +545,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
         const int t = (int)(kt_ % taps);
         const int k = (int)(kt_ / taps);
         const float* src = ws + ((size_t)k * taps + t) * C64 + c;
+        // slabs are added in index order (fixed rounding), eight loads in flight at a time
         float a = 0.f;
-        for (int s = 0; s < nslabs; ++s) a += src[s * stride];
+        int s = 0;
+        for (; s + 8 <= nslabs; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; s < nslabs; ++s) a += src[(size_t)s * stride];
         dw[((size_t)k * Cin + c) * taps + t] = a;
     }
 }
@@ -442,11 +575,13 @@ template <int TAPS, int STRIDE> void pick_tile_w(int OH, int OW, int* th, int* t
     *th = bth; *tw = btw;
 }
 
+// Workgroups per weight block: one per CU share (256 / blocks)
 int slices_for(int K, int Cin) {
     const int pairs = ((K + 63) / 64) * ((Cin + 63) / 64);
     int n = 256 / pairs;
     return n < 1 ? 1 : n;
 }
+
 
 template <int TAPS, int STRIDE>
 int run_wgrad(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, size_t need, int N, int IH,
@@ -534,14 +669,22 @@ int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t
     const size_t lds = 2 * (size_t)G_BUF;
     static DeviceOnce attr_set;
     if (!attr_set.done()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_dma_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_dma_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_dma_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", who, lds);
             return SF_ELAUNCH;
         }
         attr_set.mark();
     }
-    hipLaunchKernelGGL(wgrad3_dma_kernel, dim3((unsigned)(nslices * p.kt_tiles * p.ct_tiles)), dim3(NTW), lds, s, p);
+    const int pairs = p.kt_tiles * p.ct_tiles;
+    const bool queue_ok = g_dynamic_tiles.load() && (nslices & 7) == 0 && nslices <= 512 &&
+                          nslices * pairs <= STEAL_WORKERS && (p.TH + 2) * (p.TW + 2) <= 368 && p.ntiles > nslices;
+    p.qslot = queue_ok ? (int)(g_wlaunches.fetch_add(1) % SF_QUEUE_SLOTS) : -1;
+    p.shirk = g_dynamic_tiles.load() == 2;
+    if (queue_ok) hipLaunchKernelGGL(wgrad3_dma_kernel<true>, dim3((unsigned)(nslices * pairs)), dim3(NTW), lds, s, p);
+    else hipLaunchKernelGGL(wgrad3_dma_kernel<false>, dim3((unsigned)(nslices * pairs)), dim3(NTW), lds, s, p);
     const long long total = (long long)K * 9 * Cin;
     int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, ws, dw, nslices, p.K64, p.C64, K, Cin, 9);
@@ -551,6 +694,11 @@ int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t
 }
 
 }  // namespace
+
+extern "C" int sf_set_wgrad_scheduling(int dynamic) {
+    g_dynamic_tiles.store(dynamic < 0 ? 0 : dynamic > 2 ? 2 : dynamic);
+    return SF_OK;
+}
 
 extern "C" size_t sf_wgrad3x3_workspace_bytes(int N, int H, int W, int K, int Cin) {
     (void)N; (void)H; (void)W;

@@ -80,6 +80,11 @@ class FlatAdam:
         self._spans: List[Tuple[int, int, int]] = []
         self._calls = 0                          # step() calls so far
         self._seen = [0] * len(self.params)      # step() calls in which the parameter had a gradient
+        # views made once: the usual step (every parameter has a gradient) then costs the host one
+        # multi-tensor copy and a handful of launches, no per-parameter slicing
+        self._small_views = [self.gsmall[o:o + n].view(p.shape) for p, (o, n) in zip(self.small, self.ranges)]
+        self._big_views = [(self.flat[o:o + n], self.m[o:o + n], self.v[o:o + n]) for (o, n) in self.ranges[len(self.small):]]
+        self._uniform = True                     # every parameter has taken part in every step so far
 
     @property
     def t(self) -> int:
@@ -94,6 +99,11 @@ class FlatAdam:
         """Small gradients -> self.gsmall (zeros for a parameter that received none, so that the
         buffer a data-parallel all-reduce sends is defined everywhere); records the spans of
         parameters that did receive one for step()."""
+        if self._uniform and all(p.grad is not None for p in self.small):
+            if self.small:
+                torch._foreach_copy_(self._small_views, [p.grad for p in self.small])
+            self._spans = [(0, self.n_small, 0)] if self.n_small else []
+            return
         dst, src, spans = [], [], []
         for i, (p, (o, n)) in enumerate(zip(self.small, self.ranges)):
             if p.grad is None:
@@ -120,19 +130,20 @@ class FlatAdam:
             ops.adam_guarded(self.flat[a:e], self.gsmall[a:e], self.m[a:e], self.v[a:e], self.lr, b1, b2, self.eps,
                              self.state, found_inf, grad_scale, step_offset=off)
         ns = len(self.small)
-        for i, (p, (o, n)) in enumerate(zip(self.big, self.ranges[ns:])):
+        for i, (p, (fl, m, v)) in enumerate(zip(self.big, self._big_views)):
             if p.grad is None:
                 continue
             shadow = ops.weight_shadow(p) if self.shadow_big else None
-            ops.adam_guarded(self.flat[o:o + n], p.grad.contiguous().view(-1), self.m[o:o + n], self.v[o:o + n], self.lr,
-                             b1, b2, self.eps, self.state, found_inf, grad_scale, shadow=shadow,
-                             step_offset=self._seen[ns + i] - self._calls)
+            ops.adam_guarded(fl, p.grad.contiguous().view(-1), m, v, self.lr, b1, b2, self.eps, self.state, found_inf,
+                             grad_scale, shadow=shadow, step_offset=self._seen[ns + i] - self._calls)
             if shadow is not None:
                 ops.mark_shadow_current(p)
         self._calls += 1
         for i, p in enumerate(self.params):
             if p.grad is not None:
                 self._seen[i] += 1
+            else:
+                self._uniform = False
         ops.bump_weight_epoch()
 
     def grads(self) -> List[torch.Tensor]:
@@ -163,6 +174,7 @@ class FlatAdam:
         self.state[0] = int(state["t"])
         self._calls = int(state["t"])
         self._seen = [self._calls] * len(self.params)
+        self._uniform = True
 
     def range_of(self, p: torch.Tensor):
         for q, r in zip(self.params, self.ranges):
@@ -213,7 +225,7 @@ class Trainer:
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.world = dist.get_world_size() if self.distributed else 1
         self.nan_flags = torch.zeros(4, device=self.device, dtype=torch.int32)
-        self.found_inf = torch.zeros(1, device=self.device, dtype=torch.int32)
+        self.found_inf = torch.zeros(2, device=self.device, dtype=torch.int32)    # generator / discriminator gradients
         self._pending: List = []
         self._reduce_now = False
         if self.distributed:
@@ -221,6 +233,10 @@ class Trainer:
             # hosts without a device transport) gets the gradients staged through host memory
             self._device_collectives = dist.get_backend() == "nccl"
             self._comm_stream = torch.cuda.Stream(device=self.device) if self._device_collectives else None
+            # communication kernels will hold CUs while the backward runs: the weight-gradient kernel
+            # deals its tiles through a queue too (the 3x3 / 4x4 forward and data-gradient kernels
+            # always do; for the weight gradient it costs the bit-reproducible summation order)
+            ops.set_wgrad_scheduling(bool(scfg.get("dp_dynamic_wgrad", True)))
             self._broadcast_initial_state()
             self._install_early_reduce()
 
@@ -262,7 +278,8 @@ class Trainer:
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ready)
                 work = dist.all_reduce(t, async_op=True)
-            t.record_stream(self._comm_stream)
+            # (no record_stream: the communication stream only carries the wait, the process group
+            # keeps `t` alive until its own stream is done, and _wait_reduces orders every later use)
             self._pending.append(work)
         else:
             host = t.detach().to("cpu")
@@ -339,6 +356,19 @@ class Trainer:
                 ld["total"] = loss_g
             ops.nan_inf_flag(loss_g.detach().reshape(1), self.nan_flags[_FLAG_LOSS:_FLAG_LOSS + 1])
         (loss_g / self.accum).backward()
+        # The generator's update needs nothing from the discriminator pass below (which works on
+        # pred.detach() and never reads a generator parameter), so it is issued first: its large
+        # kernels keep the GPU busy while the host works through the many small launches of the
+        # discriminator pass.  Data parallel, the big gradients are already on their way (hooks) and
+        # the rest of a network travels as one buffer; every rank issues the same collectives in the
+        # same order for a given batch index.
+        scale = 1.0 / self.world if self.distributed else 1.0
+        if stepping:
+            self.opt_g.gather()
+            if self.distributed:
+                self._all_reduce(self.opt_g.gsmall)
+                self._wait_reduces()
+            self._step(self.opt_g, scale, 0)
         if d_batch:
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp), torch.set_grad_enabled(d_live):
                 pred_real = self.discriminator(output_image)
@@ -350,39 +380,35 @@ class Trainer:
             if d_live:
                 (loss_d / self.accum).backward()
         if stepping:
-            scale = 1.0
-            self.opt_g.gather()
             if d_batch:
                 self.opt_d.gather()
-            if self.distributed:
-                # big gradients are already on their way (hooks); everything else is one buffer per
-                # network.  Every rank issues the same collectives in the same order for a given
-                # batch index.
-                self._all_reduce(self.opt_g.gsmall)
-                if d_batch:
+                if self.distributed:
                     self._all_reduce(self.opt_d.gsmall)
                     for p in self.opt_d.big:
                         if p.grad is not None:
                             self._all_reduce(p.grad)
-                self._wait_reduces()
-                scale = 1.0 / self.world
-            found = None
-            if self.use_amp:
-                # after the exchange, so that every rank takes the same decision
-                found = self.found_inf
-                found.zero_()
-                for g in self.opt_g.grads() + (self.opt_d.grads() if d_batch else []):
-                    ops.nan_inf_flag(g, found)
-            self.opt_g.step(scale, found)
-            if d_batch:
-                self.opt_d.step(scale, found)
-            self.opt_g.zero_grad()
+                    self._wait_reduces()
+                self._step(self.opt_d, scale, 1)
             if self.use_gan:
                 self.opt_d.zero_grad()
         if self.use_gan:
             self.discriminator.last_record = None
         self.batch_idx += 1
         return ld
+
+    def _step(self, opt: FlatAdam, scale: float, which: int):
+        """Adam step of one network from its gathered (and, data-parallel, exchanged) gradients.
+        With mixed precision the step is skipped on the device when these gradients hold Inf/NaN:
+        GradScaler.step decides per optimiser (src/train.py:255-260); the check runs after the
+        exchange, so every rank takes the same decision."""
+        found = None
+        if self.use_amp:
+            found = self.found_inf[which:which + 1]
+            found.zero_()
+            for g in opt.grads():
+                ops.nan_inf_flag(g, found)
+        opt.step(scale, found)
+        opt.zero_grad()
 
     # ---- epochs ---------------------------------------------------------------------------
     def train_epoch(self, dataloader) -> Dict[str, float]:

@@ -207,3 +207,29 @@ def test_full_size_output_conv_passes(sf, dtype):
     assert _rel(db, dy.double().sum().view(1)) <= 1e-4
     # the channel sums are those of the input gradient as stored (rounded to the storage dtype)
     assert _rel(dsum, dx.double().sum((0, 1, 2))) <= 1e-4
+
+
+def test_full_size_wgrad_with_tile_stealing(sf):
+    """sf_wgrad3x3 with stealing allowed (the data-parallel setting) at the two benchmark shapes, and
+    with every second workgroup leaving its whole list to the others (so that tiles really are
+    stolen): same result as the fixed slices up to the f32 summation order (1e-5 of the maximum), and
+    repeated launches reuse the counter slots without leaving them dirty."""
+    ops = sf.ops
+    for (N, H, C, K) in ((160, 100, 128, 256), (32, 400, 64, 64), (3, 50, 64, 128)):
+        torch.manual_seed(23)
+        x = torch.randn(N, H, H, C, device=DEV).to(torch.bfloat16)
+        dz = torch.randn(N, H, H, K, device=DEV).to(torch.bfloat16)
+        ref = torch.empty(K, C, 3, 3, device=DEV)
+        ops.wgrad3x3(x, dz, ref)
+        try:
+            for mode in (1, 2):
+                ops.set_wgrad_scheduling(mode)
+                for _ in range(70):          # more launches than counter slots
+                    dw = torch.empty(K, C, 3, 3, device=DEV)
+                    ops.wgrad3x3(x, dz, dw)
+                assert _rel(dw, ref) <= 1e-5, (mode, N, H, C, K)
+        finally:
+            ops.set_wgrad_scheduling(0)
+        again = torch.empty(K, C, 3, 3, device=DEV)
+        ops.wgrad3x3(x, dz, again)
+        assert torch.equal(again, ref)      # fixed slices: bit-reproducible
