@@ -302,7 +302,7 @@ class ResidentStreamflowDataset:
             raise IndexError("window index out of range")
         D, C, H, W = self.frames.shape
         rows = np.concatenate([(idx[:, None] + np.arange(T)[None]).reshape(-1), idx + T])
-        rows_d = torch.from_numpy(rows).to(self.device, non_blocking=True)
+        rows_d = ops.upload(torch.from_numpy(rows), self.device)
         images = torch.empty((B, T, C, H, W), device=self.device, dtype=torch.float32)
         target = torch.empty((B, 1, H, W), device=self.device, dtype=torch.float32)
         ops.gather_frames(self.frames, C * H * W, D, rows_d[:B * T], C * H * W, images)

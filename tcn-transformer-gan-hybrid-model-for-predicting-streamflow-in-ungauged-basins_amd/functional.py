@@ -537,7 +537,7 @@ class PackedStations:
             buf[: 2 * S] = np.asarray(pos, dtype=np.int32).reshape(-1)
             buf[2 * n: 2 * n + S] = np.asarray(run, dtype=np.float32).reshape(-1).view(np.int32)
         buf[3 * n + 1:] = np.cumsum(counts)
-        d = torch.from_numpy(buf).to(device, non_blocking=True)
+        d = ops.upload(torch.from_numpy(buf), device)
         return cls(d[: 2 * n].view(-1, 2), d[2 * n: 3 * n].view(torch.float32), d[3 * n:], S)
 
 
@@ -553,14 +553,14 @@ def pack_stations(positions: Sequence[torch.Tensor], runoffs: Sequence[torch.Ten
     offs = [0]
     for c in counts:
         offs.append(offs[-1] + c)
-    buf = torch.zeros(max(S, 1) * 3 + B + 1, dtype=torch.int32)
+    buf = torch.zeros(max(S, 1) * 3 + B + 1, dtype=torch.int32, pin_memory=torch.device(device).type == "cuda")
     if S:
         pos = torch.cat([p.reshape(-1, 2).to(torch.int32).cpu() for p, c in zip(positions, counts) if c], dim=0)
         run = torch.cat([r.reshape(-1).to(torch.float32).cpu() for r, c in zip(runoffs, counts) if c], dim=0)
         buf[: 2 * S] = pos.reshape(-1)
         buf[2 * S: 3 * S] = run.view(torch.int32)
     buf[3 * max(S, 1):] = torch.tensor(offs, dtype=torch.int32)
-    d = buf.to(device, non_blocking=True)
+    d = ops.upload(buf, device)
     n = max(S, 1)
     return d[: 2 * n].view(-1, 2), d[2 * n: 3 * n].view(torch.float32), d[3 * n:], S
 

@@ -340,6 +340,32 @@ def conv3x3_stage_weights(wp: torch.Tensor, C: int, K: int) -> torch.Tensor:
 STAGE_CONV_WEIGHTS = os.environ.get("SF_STAGE_CONV_WEIGHTS", "1") != "0"   # debug switch for A/B timing
 
 
+_UPLOAD_STREAMS: dict = {}
+
+
+def upload(host: torch.Tensor, device) -> torch.Tensor:
+    """A small host array -> device memory without making the host wait.  A host-to-device copy
+    queued on the compute stream can block the calling thread until the kernels queued before it
+    have run (seen with pageable and with page-locked sources once a second stream is active), which
+    costs the step the host's lead over the GPU.  So the array is staged in page-locked memory and
+    copied on a stream of its own, which the compute stream then waits for."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return host.to(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    up = _UPLOAD_STREAMS.get(idx)
+    if up is None:
+        up = _UPLOAD_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    if not host.is_pinned():
+        host = torch.empty(host.shape, dtype=host.dtype, pin_memory=True).copy_(host)
+    cur = torch.cuda.current_stream(idx)
+    with torch.cuda.stream(up):
+        d = host.to(dev, non_blocking=True)
+    cur.wait_stream(up)
+    d.record_stream(cur)
+    return d
+
+
 def set_wgrad_scheduling(dynamic):
     """See sf_set_wgrad_scheduling: True / 1 when other kernels (RCCL's) share the GPU's CUs, 2 for the
     self-test in which every second workgroup leaves its tiles to the others."""

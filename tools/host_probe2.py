@@ -23,7 +23,38 @@ tr = training.Trainer(cfg, device="cuda", distributed=True if reh else None)
 def step(i):
     b = dev[i % 3]
     tr.train_step(b["images"], b["output_image"], b["station_positions"], b["stations"])
+TIMES = {}
+def timed(obj, name, label=None):
+    fn = getattr(obj, name)
+    label = label or name
+    def w(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            TIMES[label] = TIMES.get(label, 0.0) + time.perf_counter() - t
+    (setattr if isinstance(obj, type) else object.__setattr__)(obj, name, w)
+if os.environ.get("TIMERS") == "1":
+    for n in ("_all_reduce", "_wait_reduces", "_step"):
+        timed(tr, n)
+    timed(tr.opt_g, "gather", "gather_g")
+    timed(torch.Tensor, "backward")
+    timed(tr.model, "forward", "model_forward")
+    if tr.use_gan:
+        timed(tr.discriminator, "forward", "disc_forward")
+        timed(tr.opt_d, "gather", "gather_d")
+        timed(tr.opt_d, "zero_grad", "zero_grad_d")
+        timed(tr.gan_loss_fn, "gan_loss")
+        timed(tr.gan_loss_fn, "discriminator_loss")
+        timed(tr, "_set_d_requires_grad")
+    timed(tr.loss_fn, "forward", "loss_forward")
+    timed(sf.ops, "nan_inf_flag")
+    timed(sf.ops, "image_station_loss")
+    timed(importlib.import_module(bench.PKG + ".functional"), "pack_stations")
+    timed(torch.Tensor, "to", "Tensor.to")
+    timed(tr, "train_step")
 for i in range(4): step(i)
+TIMES.clear()
 torch.cuda.synchronize()
 N = 12
 t0 = time.perf_counter()
@@ -31,10 +62,12 @@ for i in range(N): step(i)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+if TIMES:
+    print({k: round(1e3 * v / N, 3) for k, v in TIMES.items()}, "ms/step on the host")
 if os.environ.get("PROFILE_HOST") == "1":
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()
     for i in range(N): step(i)
     pr.disable(); torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+    pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(25)
 print(f"host enqueue {1e3 * (t1 - t0) / N:.2f} ms/step, with GPU drain {1e3 * (t2 - t0) / N:.2f} ms/step")
