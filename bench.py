@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "tcn-transformer-gan-hybrid-model-for-predicting-streamflow-in-ungauged-basins_amd"
 
-PMC_SUMMARY = "r1z_pmc_hbm_traffic.json"
+PMC_SUMMARY = "r2_pmc_hbm_traffic.json"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (spec)
 
 

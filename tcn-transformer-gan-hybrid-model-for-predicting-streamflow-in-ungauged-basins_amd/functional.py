@@ -71,7 +71,8 @@ class EncoderFn(torch.autograd.Function):
             K = wt.shape[0]
             Kpad = ops.roundup(K, 8)
             C = a.shape[-1]
-            wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), False, Kpad, C)
+            wp = ops.derived(wt, ("pack3", cdtype, False, Kpad, C),
+                             lambda: ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), False, Kpad, C))
             M = N * h * w
             if (l == 0 and L > 1 and not ctx.needs_input_grad[0] and K == Kpad and wt.shape[1] <= 14
                     and ops.enc1_ok(a, K) and not ops.FORCE_GENERIC_CONV):
@@ -87,7 +88,8 @@ class EncoderFn(torch.autograd.Function):
                 h, w = h // 2, w // 2
                 continue
             z = torch.empty((N, h, w, Kpad), device=x.device, dtype=cdtype)
-            ops.conv3x3(a, ops.conv3x3_stage_weights(wp, C, Kpad), z, Kpad, flop_c=wt.shape[1], flop_k=K)
+            wst = ops.derived(wt, ("stage3", cdtype, False, Kpad, C), lambda: ops.conv3x3_stage_weights(wp, C, Kpad))
+            ops.conv3x3(a, wst, z, Kpad, flop_c=wt.shape[1], flop_k=K)
             ws = None
             if training:
                 ws = ops.bn_ws(Kpad, x.device)
@@ -132,9 +134,10 @@ class EncoderFn(torch.autograd.Function):
             ops.wgrad3x3(a, dz, dw)
             grads[5 * l], grads[5 * l + 1], grads[5 * l + 2] = dw, dgamma, dbeta
             if l > 0 or ctx.needs_input_grad[0]:
-                wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), True, C, Kpad)
+                wT = ops.derived(wt, ("stage3", cdtype, True, C, Kpad), lambda: ops.conv3x3_stage_weights(
+                    ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(9)), True, C, Kpad), Kpad, C))
                 da = torch.empty((N, h, w, C), device=dz.device, dtype=cdtype)
-                ops.conv3x3(dz, ops.conv3x3_stage_weights(wT, Kpad, C), da, C, dgrad=True, flop_c=K, flop_k=cin_real)
+                ops.conv3x3(dz, wT, da, C, dgrad=True, flop_c=K, flop_k=cin_real)
                 if l > 0:
                     dy = da
                 else:
@@ -301,31 +304,37 @@ class DecoderFn(torch.autograd.Function):
         Hp = ops.roundup(Hc, 8)
         src = ops.nchw_to_nhwc(x.contiguous().float(), cdtype, C)
         # rows (tap, k): w9[t * Hp + k][c] = w1[k][c][t]; padded output channels are zero rows
-        if Hp == Hc:
-            w9 = w1.detach().reshape(Hc, C, 9).permute(2, 0, 1).contiguous()
-        else:
-            w9 = torch.zeros((9, Hp, C), device=x.device, dtype=torch.float32)
-            w9[:, :Hc] = w1.detach().reshape(Hc, C, 9).permute(2, 0, 1)
-        w9 = w9.view(9 * Hp, C, 1, 1)
-        w9p = ops.pack_conv_weight(w9, cdtype, [0], False, 9 * Hp, C)
+        def tap_major():
+            if Hp == Hc:
+                w9 = w1.detach().reshape(Hc, C, 9).permute(2, 0, 1).contiguous()
+            else:
+                w9 = torch.zeros((9, Hp, C), device=x.device, dtype=torch.float32)
+                w9[:, :Hc] = w1.detach().reshape(Hc, C, 9).permute(2, 0, 1)
+            return w9.view(9 * Hp, C, 1, 1)
+
+        w9p = ops.derived(w1, ("w9p", cdtype, Hp), lambda: ops.pack_conv_weight(tap_major(), cdtype, [0], False, 9 * Hp, C))
+        w9T = None
+        if ctx.needs_input_grad[0]:
+            w9T = ops.derived(w1, ("w9T", cdtype, Hp), lambda: ops.pack_conv_weight(tap_major(), cdtype, [0], True, C, 9 * Hp))
         y9 = torch.empty((B, h, w, 9 * Hp), device=x.device, dtype=torch.float32)
         ops.conv_fprop(src, w9p, y9, _pix_geom(B, h, w, C), 9 * Hp)
         bp1 = _pad_vec(b1.detach(), Hp)
         h1 = ops.upconv3_fwd(y9.view(B, h, w, 9, Hp), bp1, OH, OW, cdtype, relu=True)
-        w2p = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), False, Hp, Hp)
+        w2p = ops.derived(w2, ("pack3", cdtype, False, Hp, Hp),
+                          lambda: ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), False, Hp, Hp))
         bp2 = _pad_vec(b2.detach(), Hp)
         h2 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
         ops.conv3x3(h1, w2p, h2, Hp, bias=bp2, act=ops.ACT_RELU, flop_c=Hc, flop_k=Hc)
         w3c = w3.detach().contiguous()
         y = ops.conv_k1_fwd(h2, w3c, b3.detach().contiguous(), 1, 0)
-        ctx.save_for_backward(src, h1, h2, w3c, w9)
+        ctx.save_for_backward(src, h1, h2, w3c, w9T)
         ctx.weights = (w1, w2)
         ctx.dims = (B, C, h, w, OH, OW, Hc, Hp, cdtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        src, h1, h2, w3c, w9 = ctx.saved_tensors
+        src, h1, h2, w3c, w9T = ctx.saved_tensors
         w1, w2 = ctx.weights
         B, C, h, w, OH, OW, Hc, Hp, cdtype = ctx.dims
         dy = dy.contiguous().float()
@@ -337,7 +346,8 @@ class DecoderFn(torch.autograd.Function):
             db2 = ops.channel_sum(dz2, Hc)
         dw2 = torch.empty_like(w2)
         ops.wgrad3x3(h1, dz2, dw2)
-        w2T = ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), True, Hp, Hp)
+        w2T = ops.derived(w2, ("pack3", cdtype, True, Hp, Hp),
+                          lambda: ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), True, Hp, Hp))
         dz1 = torch.empty_like(h1)
         ops.conv3x3(dz2, w2T, dz1, Hp, dgrad=True, aux=h1, aux_mode=1, flop_c=Hc, flop_k=Hc)
         g = ops.upconv3_bwd(dz1, h, w, cdtype).view(B, h, w, 9 * Hp)
@@ -351,7 +361,6 @@ class DecoderFn(torch.autograd.Function):
         db1 = g.view(-1, 9, Hp)[:, 4, :Hc].float().sum(dim=0)
         dx = None
         if ctx.needs_input_grad[0]:
-            w9T = ops.pack_conv_weight(w9, cdtype, [0], True, C, 9 * Hp)
             dsrc = torch.empty((B, h, w, C), device=dy.device, dtype=torch.float32)
             ops.conv_fprop(g, w9T, dsrc, _pix_geom(B, h, w, 9 * Hp), C)
             dx = ops.nhwc_to_nchw(dsrc, C)

@@ -288,15 +288,18 @@ def conv4x4s2_ok(x: torch.Tensor, K: int, ldo: int) -> bool:
 
 def conv4x4s2_weights(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     """f32 OIHW 4x4 weights -> the staged bf16 operand of conv4x4s2 (forward or data gradient)."""
-    O, I = w.shape[0], w.shape[1]
-    rows, cols = (I, O) if dgrad else (O, I)
-    wp = pack_conv_weight(w.detach().contiguous(), torch.bfloat16, s2_tap_order(dgrad), dgrad, rows, cols)
-    nbytes = int(lib().sf_conv4x4s2_staged_weight_bytes(cols, rows))
-    if nbytes == 0:
-        raise RuntimeError("conv4x4s2_weights: the reduction channel count must be a multiple of 16")
-    ws = torch.empty(nbytes // 2, device=w.device, dtype=torch.bfloat16)
-    _check(lib().sf_conv4x4s2_stage_weights(_p(wp), _p(ws), cols, rows, _stream()), "sf_conv4x4s2_stage_weights")
-    return ws
+    def build():
+        O, I = w.shape[0], w.shape[1]
+        rows, cols = (I, O) if dgrad else (O, I)
+        wp = pack_conv_weight(w.detach().contiguous(), torch.bfloat16, s2_tap_order(dgrad), dgrad, rows, cols)
+        nbytes = int(lib().sf_conv4x4s2_staged_weight_bytes(cols, rows))
+        if nbytes == 0:
+            raise RuntimeError("conv4x4s2_weights: the reduction channel count must be a multiple of 16")
+        ws = torch.empty(nbytes // 2, device=w.device, dtype=torch.bfloat16)
+        _check(lib().sf_conv4x4s2_stage_weights(_p(wp), _p(ws), cols, rows, _stream()), "sf_conv4x4s2_stage_weights")
+        return ws
+
+    return derived(w, ("s2", bool(dgrad)), build)
 
 
 def conv4x4s2(x, ws, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0):
@@ -491,6 +494,20 @@ WEIGHT_EPOCH = 0     # bumped whenever an optimiser kernel rewrites parameters b
 def bump_weight_epoch():
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
+
+
+def derived(owner: torch.Tensor, key, build):
+    """A tensor computed from parameter `owner` alone (a packed / staged copy of a conv weight),
+    kept on the parameter object until the parameter changes: in place through torch (its version
+    counter), behind torch's back by an optimiser kernel (WEIGHT_EPOCH), or by moving elsewhere."""
+    ver = (WEIGHT_EPOCH, owner._version, owner.data_ptr())
+    cache = owner.__dict__.setdefault("_sf_derived", {})
+    hit = cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    t = build()
+    cache[key] = (ver, t)
+    return t
 
 
 def _shadow_key(p: torch.Tensor):

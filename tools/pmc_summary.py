@@ -18,7 +18,28 @@ import os
 import sys
 
 
+def short_name(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = name.replace("_ZN12_GLOBAL__N_1", "").split("(")[0]
+    return name.split("<")[0] if not name[:1].isdigit() else name
+
+
+def per_kernel_db(path, counter):
+    """rocpd SQLite output (rocprofv3 of ROCm 7): counter values of a dispatch are summed over their
+    instances (XCDs)."""
+    import sqlite3
+    cur = sqlite3.connect(path).cursor()
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for name, disp, val in cur.execute(
+            "select kernel_name, dispatch_id, value from counters_collection where counter_name = ?", (counter,)):
+        per[short_name(name)][disp] += val * 1024.0
+    return {k: list(d.values()) for k, d in per.items()}
+
+
 def per_kernel(directory, counter):
+    dbs = glob.glob(os.path.join(directory, "*.db")) + glob.glob(os.path.join(directory, "*", "*.db"))
+    if dbs:
+        return per_kernel_db(max(dbs, key=os.path.getmtime), counter)
     path = max(glob.glob(os.path.join(directory, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     acc = collections.defaultdict(list)
     with open(path) as f:
