@@ -23,6 +23,8 @@ __device__ __forceinline__ double block_min_d(double v, double* sm) {
     return fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
 }
 
+constexpr int GRID_YZ_MAX = 65535;   // blocks in a grid dimension other than x
+
 // grid (C, D).  out[d][c] = {sum, sumsq, min, max} over the selected pixels of plane (d, c);
 // count[d] = number of selected pixels; bad0[d] = non-finite values in channel 0 (all pixels).
 // Selection: mask > 0.5 where the date has a mask (mask_row[d] >= 0), every pixel otherwise.
@@ -118,11 +120,16 @@ __global__ __launch_bounds__(DS_NT) void gather_frames_kernel(const float* __res
 extern "C" int sf_dataset_plane_stats(const float* frames, const float* masks, const int* mask_row, int D, int C,
                                       long long HW, double* out, long long* count, int* bad0, void* stream) {
     SF_REQUIRE(frames && out && count && bad0, "sf_dataset_plane_stats: null buffer");
-    SF_REQUIRE(D >= 1 && D <= 65535 && C >= 1 && HW >= 1, "sf_dataset_plane_stats: bad shape D=%d C=%d HW=%lld", D, C, HW);
+    SF_REQUIRE(D >= 1 && C >= 1 && HW >= 1, "sf_dataset_plane_stats: bad shape D=%d C=%d HW=%lld", D, C, HW);
     SF_REQUIRE((masks != nullptr) == (mask_row != nullptr), "sf_dataset_plane_stats: masks and mask_row go together");
-    dataset_plane_stats_kernel<<<dim3(C, D), DS_NT, 0, (hipStream_t)stream>>>(frames, masks, mask_row, C, HW, out,
-                                                                           count, bad0);
-    SF_LAUNCH_CHECK("sf_dataset_plane_stats");
+    // a grid dimension other than x holds at most 65535 blocks: dates go in launches of that many
+    for (int d0 = 0; d0 < D; d0 += GRID_YZ_MAX) {
+        const int nd = D - d0 < GRID_YZ_MAX ? D - d0 : GRID_YZ_MAX;
+        dataset_plane_stats_kernel<<<dim3(C, nd), DS_NT, 0, (hipStream_t)stream>>>(
+            frames + (long long)d0 * C * HW, masks, mask_row ? mask_row + d0 : nullptr, C, HW,
+            out + (long long)d0 * C * 4, count + d0, bad0 + d0);
+        SF_LAUNCH_CHECK("sf_dataset_plane_stats");
+    }
     return SF_OK;
 }
 
@@ -130,34 +137,41 @@ extern "C" int sf_dataset_transform(float* frames, float* target, const float* m
                                     const double* a, const double* b, int normalize, float flow_threshold, int D,
                                     int C, long long HW, void* stream) {
     SF_REQUIRE(frames, "sf_dataset_transform: null frames");
-    SF_REQUIRE(D >= 1 && D <= 65535 && C >= 1 && C <= 65535 && HW >= 1, "sf_dataset_transform: bad shape D=%d C=%d HW=%lld",
+    SF_REQUIRE(D >= 1 && C >= 1 && C <= GRID_YZ_MAX && HW >= 1, "sf_dataset_transform: bad shape D=%d C=%d HW=%lld",
                D, C, HW);
     SF_REQUIRE(!normalize || (a && b), "sf_dataset_transform: normalisation needs both coefficient arrays");
     SF_REQUIRE((masks != nullptr) == (mask_row != nullptr), "sf_dataset_transform: masks and mask_row go together");
     const long long gx = (HW + DS_NT - 1) / DS_NT;
     SF_REQUIRE(gx <= 0x7fffffffLL, "sf_dataset_transform: plane too large");
-    dataset_transform_kernel<<<dim3((unsigned)gx, C, D), DS_NT, 0, (hipStream_t)stream>>>(
-        frames, target, masks, mask_row, a, b, normalize, flow_threshold, C, HW);
-    SF_LAUNCH_CHECK("sf_dataset_transform");
+    for (int d0 = 0; d0 < D; d0 += GRID_YZ_MAX) {
+        const int nd = D - d0 < GRID_YZ_MAX ? D - d0 : GRID_YZ_MAX;
+        dataset_transform_kernel<<<dim3((unsigned)gx, C, nd), DS_NT, 0, (hipStream_t)stream>>>(
+            frames + (long long)d0 * C * HW, target ? target + (long long)d0 * HW : nullptr, masks,
+            mask_row ? mask_row + d0 : nullptr, a, b, normalize, flow_threshold, C, HW);
+        SF_LAUNCH_CHECK("sf_dataset_transform");
+    }
     return SF_OK;
 }
 
 extern "C" int sf_gather_frames(const float* src, long long src_stride, long long n_src, const long long* rows, int n,
                                 long long n_elems, float* dst, void* stream) {
     SF_REQUIRE(src && rows && dst, "sf_gather_frames: null buffer");
-    SF_REQUIRE(n >= 1 && n <= 65535, "sf_gather_frames: n=%d out of range", n);
+    SF_REQUIRE(n >= 1, "sf_gather_frames: n=%d out of range", n);
     SF_REQUIRE(n_elems >= 1 && n_elems <= src_stride && n_src >= 1,
                "sf_gather_frames: frame of %lld floats, stride %lld, %lld source frames", n_elems, src_stride, n_src);
     const bool vec = n_elems % 4 == 0 && src_stride % 4 == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0;
     const long long n_v = vec ? n_elems / 4 : n_elems;
     long long chunks = (n_v + DS_NT * 4 - 1) / (DS_NT * 4);   // ~4 accesses per thread
     if (chunks > 1024) chunks = 1024;
-    if (vec)
-        gather_frames_kernel<float4><<<dim3((unsigned)chunks, n), DS_NT, 0, (hipStream_t)stream>>>(
-            src, src_stride, n_src, rows, n_elems, n_v, dst);
-    else
-        gather_frames_kernel<float><<<dim3((unsigned)chunks, n), DS_NT, 0, (hipStream_t)stream>>>(
-            src, src_stride, n_src, rows, n_elems, n_v, dst);
-    SF_LAUNCH_CHECK("sf_gather_frames");
+    for (int i0 = 0; i0 < n; i0 += GRID_YZ_MAX) {
+        const int ni = n - i0 < GRID_YZ_MAX ? n - i0 : GRID_YZ_MAX;
+        if (vec)
+            gather_frames_kernel<float4><<<dim3((unsigned)chunks, ni), DS_NT, 0, (hipStream_t)stream>>>(
+                src, src_stride, n_src, rows + i0, n_elems, n_v, dst + (long long)i0 * n_elems);
+        else
+            gather_frames_kernel<float><<<dim3((unsigned)chunks, ni), DS_NT, 0, (hipStream_t)stream>>>(
+                src, src_stride, n_src, rows + i0, n_elems, n_v, dst + (long long)i0 * n_elems);
+        SF_LAUNCH_CHECK("sf_gather_frames");
+    }
     return SF_OK;
 }

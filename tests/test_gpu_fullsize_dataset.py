@@ -71,3 +71,27 @@ def test_year_of_frames(sf):
     tout = torch.empty(32, 1, H, W, device=DEV)
     ops.gather_frames(target, H * W, D, starts + 5, H * W, tout)
     assert torch.equal(torch.nan_to_num(tout, nan=-7.0), torch.nan_to_num(target[starts + 5], nan=-7.0))
+
+
+def test_more_dates_and_rows_than_a_grid_dimension_holds(sf):
+    """70 000 dates / gathered rows (a grid's y and z dimensions hold 65 535 blocks: the wrappers
+    launch in chunks): statistics against float64 reductions, transform and gather bit-exact."""
+    ops = sf.ops
+    D, C, H, W = 70000, 2, 2, 4
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randn(D, C, H, W, generator=g).to(DEV)
+    stats, count, bad0 = ops.dataset_plane_stats(frames, None, None)
+    f64 = frames.double().view(D, C, -1)
+    assert torch.allclose(stats[:, :, 0], f64.sum(-1), rtol=1e-12, atol=1e-12)
+    assert torch.equal(stats[:, :, 2], f64.min(-1).values) and torch.equal(stats[:, :, 3], f64.max(-1).values)
+    assert int(count.min()) == H * W and int(count.max()) == H * W and int(bad0.sum()) == 0
+    rows = torch.randperm(D, generator=g).to(DEV)
+    out = torch.empty(D, C * H * W, device=DEV)
+    ops.gather_frames(frames, C * H * W, D, rows, C * H * W, out)
+    assert torch.equal(out, frames.view(D, -1)[rows])
+    a = torch.tensor([0.25, -1.0], dtype=torch.float64, device=DEV)
+    b = torch.tensor([2.0, 0.5], dtype=torch.float64, device=DEV)
+    want = ((frames.double() - a.view(1, C, 1, 1)) / b.view(1, C, 1, 1)).float()
+    target = torch.empty(D, 1, H, W, device=DEV)
+    ops.dataset_transform(frames, target, None, None, a, b, 0.0)
+    assert torch.equal(frames, want) and torch.equal(target[:, 0], want[:, 0])
