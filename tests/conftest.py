@@ -54,6 +54,19 @@ def close(a, b, rtol=1e-5):
     assert err <= rtol, f"max rel-to-max err {err:.3e} > {rtol}"
 
 
+def close_elementwise(a, b, rtol=1e-4, atol_frac=2e-6):
+    """Element-wise |a-b| <= rtol |b| + atol_frac max|b| (numpy.allclose with the absolute term tied
+    to the tensor's scale): unlike close(), small elements are held to their own size, down to the
+    cancellation noise of an f32 sum (a few 1e-6 of the largest element)."""
+    a, b = _np(a), _np(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.size == 0:
+        return
+    bound = rtol * np.abs(b) + atol_frac * max(np.abs(b).max(), 1e-30)
+    excess = np.abs(a - b) - bound
+    assert excess.max() <= 0, f"{int((excess > 0).sum())}/{b.size} elements beyond rtol {rtol} + {atol_frac} of max"
+
+
 def close_robust(a, b, rtol=1e-5, frac=0.01, loose=0.05):
     """As close(), but tolerates a small fraction of outliers (up to `loose`): a ReLU /
     max-pool decision on a pre-activation within rounding of zero flips between two

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import goldgen as G
-from conftest import close, close_robust, golden, load_pkg
+from conftest import close, close_elementwise, close_robust, golden, load_pkg
 from oracle import streamflow_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -75,6 +75,7 @@ def test_encoder_train_f32(sf, size):
     x = G.gold_tensor(f"enc/x{size}", (2, 4, size, size)).to(DEV)
     y = enc(x)
     close(y, g[f"train{size}"], 1e-5)
+    close_elementwise(y, g[f"train{size}"])
     sd = enc.state_dict()
     close(sd["encoder.1.running_mean"], g[f"rm1_{size}"], 1e-5)
     close(sd["encoder.1.running_var"], g[f"rv1_{size}"], 1e-5)
@@ -135,6 +136,7 @@ def test_temporal_f32(sf, kind):
     x = x0.clone().requires_grad_(True)
     y = mod(x)
     close(y, g[f"{kind}_y"], 1e-5)
+    close_elementwise(y, g[f"{kind}_y"])
     (y * G.gold_tensor("tmp/gy", (B, Hd)).to(DEV)).sum().backward()
     close(x.grad, g[f"{kind}_gx"], 5e-5)
     for n, p in mod.named_parameters():
@@ -175,6 +177,7 @@ def test_decoder_f32(sf, oh):
     x = G.gold_tensor("dec/x", (2, 16, 32, 32)).to(DEV).requires_grad_(True)
     y = dec(x)
     close(y, g[f"y{oh}"], 1e-5)
+    close_elementwise(y, g[f"y{oh}"])
     (y * G.gold_tensor(f"dec/gy{oh}", tuple(y.shape)).to(DEV)).sum().backward()
     close_robust(x.grad, g[f"gx{oh}"], 1e-4)
     for n, p in dec.named_parameters():
@@ -191,6 +194,7 @@ def test_discriminator_f32(sf, size):
     x = G.gold_tensor(f"disc/x{size}", (2, 1, size, size)).to(DEV).requires_grad_(True)
     y = d(x)
     close(y, g[f"y{size}"], 2e-5)
+    close_elementwise(y, g[f"y{size}"], atol_frac=4e-6)
     (y * G.gold_tensor(f"disc/gy{size}", tuple(y.shape)).to(DEV)).sum().backward()
     close_robust(x.grad, g[f"gx{size}"], 2e-4)
     sd = d.state_dict()
@@ -330,7 +334,9 @@ def test_generator_full_size_f32_and_bf16(sf):
     m.eval()
     x = G.gold_tensor("gen_full/x", (1, 5, 10, 200, 200)).to(DEV)
     with torch.no_grad():
-        close(m(x), g["full_eval"], 1e-5)
+        y32 = m(x)
+        close(y32, g["full_eval"], 1e-5)
+        close_elementwise(y32, g["full_eval"])
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y16 = m(x)
     close(y16, g["full_eval"], 3e-2)  # stated bf16 tolerance: 3e-2 of the output's max
