@@ -57,16 +57,22 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 
 // Few channels (Cpad <= 16, bf16): a thread converts 4 consecutive pixels -- one float4 load per
 // channel (a wave reads 1 KB runs of each channel plane), 4 x Cpad contiguous bf16 out.
-template <int CP>
+// CR > 0: the real channel count at compile time (only those planes are loaded); CR = 0: C at run
+// time, padding channels re-read plane 0 and discard it.
+template <int CP, int CR>
 __global__ __launch_bounds__(NT) void nchw_to_nhwc_px4_kernel(const float* __restrict__ in, bf16* __restrict__ out,
-                                                              unsigned nquads, int C, unsigned HW) {
+                                                              unsigned nquads, int Crun, unsigned HW) {
+    const int C = CR ? CR : Crun;
     const unsigned q = blockIdx.x * NT + threadIdx.x;
     if (q >= nquads) return;
     const unsigned pix = q * 4, n = pix / HW, hw = pix - n * HW;
     const float* src = in + (size_t)n * C * HW + hw;
     float4 v[CP];
 #pragma unroll
-    for (int c = 0; c < CP; ++c) v[c] = *reinterpret_cast<const float4*>(src + (size_t)(c < C ? c : 0) * HW);
+    for (int c = 0; c < CP; ++c) {
+        if (CR && c >= CR) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else v[c] = *reinterpret_cast<const float4*>(src + (size_t)(c < C ? c : 0) * HW);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -461,10 +467,13 @@ extern "C" int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int
         const unsigned nquads = (unsigned)(npix / 4);
         const unsigned grid = (nquads + NT - 1) / NT;
         if (Cpad == 8)
-            hipLaunchKernelGGL(nchw_to_nhwc_px4_kernel<8>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
+            hipLaunchKernelGGL((nchw_to_nhwc_px4_kernel<8, 0>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
+                               nquads, C, (unsigned)HWi);
+        else if (C == 10)     // the reference's ten input bands
+            hipLaunchKernelGGL((nchw_to_nhwc_px4_kernel<16, 10>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
                                nquads, C, (unsigned)HWi);
         else
-            hipLaunchKernelGGL(nchw_to_nhwc_px4_kernel<16>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
+            hipLaunchKernelGGL((nchw_to_nhwc_px4_kernel<16, 0>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
                                nquads, C, (unsigned)HWi);
         SF_LAUNCH_CHECK("sf_nchw_to_nhwc");
         return SF_OK;
