@@ -788,11 +788,30 @@ __global__ __launch_bounds__(NT) void pw1_bwd_fused_kernel(const T* __restrict__
 // (PatchGAN head, R = 4, stride 1).  Weights sit in LDS as [tap][channel]; loads of a work item
 // are issued together with clamped / zero-chunk addresses; 32-bit indices.
 constexpr int HEAD_MAX_W = 16 * 512;  // taps x channels the LDS weight copy holds
+#ifndef SF_HEAD_GRID
+#define SF_HEAD_GRID 768
+#endif
+constexpr int HEAD_GRID_MAX = SF_HEAD_GRID;   // workgroups of the head kernels (three per CU)
 
 __device__ __forceinline__ void head_stage_weights(float* sw, const float* __restrict__ w, int C, int Creal, int RS) {
-    for (int i = threadIdx.x; i < RS * C; i += blockDim.x) {
-        const int t = i / C, c = i - t * C;
-        sw[i] = c < Creal ? w[c * RS + t] : 0.f;
+    if (RS == 16 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        // a thread takes one channel's 16 taps (64 contiguous bytes) and scatters them over the tap rows
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                v[q] = c < Creal ? *reinterpret_cast<const float4*>(w + (size_t)c * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sw[(4 * q + 0) * C + c] = v[q].x; sw[(4 * q + 1) * C + c] = v[q].y;
+                sw[(4 * q + 2) * C + c] = v[q].z; sw[(4 * q + 3) * C + c] = v[q].w;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < RS * C; i += blockDim.x) {
+            const int t = i / C, c = i - t * C;
+            sw[i] = c < Creal ? w[c * RS + t] : 0.f;
+        }
     }
     __syncthreads();
 }
@@ -1175,8 +1194,9 @@ extern "C" int sf_conv_k1_fwd(const void* x, int dtype, const float* w, const fl
         return SF_OK;
     }
     if (head_ok(dtype, C, R, total)) {
+        // every workgroup stages the 32 KB of weights first: few, looping workgroups amortise that
         const int ppb = NT / (C / epc);
-        long long grid = (total + ppb - 1) / ppb; if (grid > 8192) grid = 8192;
+        long long grid = (total + ppb - 1) / ppb; if (grid > HEAD_GRID_MAX) grid = HEAD_GRID_MAX;
         DISPATCH_T(dtype, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)stream,
                                              (const T*)x, w, b, y, (unsigned)total, H, W, C, Creal, R, pad, OH, OW));
         SF_LAUNCH_CHECK("sf_conv_k1_fwd");
@@ -1206,7 +1226,7 @@ extern "C" int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* 
     if (head_ok(dtype, C, R, (long long)N * H * W)) {
         const long long items = (long long)N * H * W;
         const int ppb = NT / (C / epc);
-        long long grid = (items + ppb - 1) / ppb; if (grid > 8192) grid = 8192;
+        long long grid = (items + ppb - 1) / ppb; if (grid > HEAD_GRID_MAX) grid = HEAD_GRID_MAX;
         DISPATCH_T(dtype, hipLaunchKernelGGL(head_bwd_data_kernel<T>, dim3((unsigned)grid), dim3(NT), 0,
                                              (hipStream_t)stream, dy, w, (const T*)aux, (T*)dx, (unsigned)items, H, W, C,
                                              Creal, R, pad, OH, OW));
