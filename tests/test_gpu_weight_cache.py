@@ -1,0 +1,67 @@
+"""Packed / staged conv weights are cached on the parameter (ops.derived): the cache must follow every
+way a parameter changes -- an in-place torch update (version counter), an optimiser kernel writing
+behind torch's back (ops.WEIGHT_EPOCH) and load_state_dict -- and a write through `.data`, which
+torch does not count, after ops.bump_weight_epoch()."""
+import pytest
+import torch
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def sf():
+    return load_pkg()
+
+
+def _fresh(sf, make, x):
+    """Output of a module built anew from the same state (no cache to go stale)."""
+    def run(state):
+        m = make()
+        m.load_state_dict(state)
+        m.train()
+        with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            return m(x).float()
+    return run
+
+
+@pytest.mark.parametrize("which", ["discriminator", "encoder"])
+def test_cached_weights_follow_the_parameter(sf, which):
+    torch.manual_seed(3)
+    if which == "discriminator":
+        make = lambda: sf.PatchDiscriminator(1, 64).to(DEV)
+        x = torch.randn(2, 1, 64, 64, device=DEV)
+    else:
+        make = lambda: sf.CNNEncoder(16, 64, 2).to(DEV)
+        x = torch.randn(2, 16, 64, 64, device=DEV)
+    m = make()
+    m.train()
+    fresh = _fresh(sf, make, x)
+
+    def out():
+        with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            return m(x).float()
+
+    def state():
+        return {k: v.clone() for k, v in m.state_dict().items()}
+
+    convs = [p for n, p in m.named_parameters() if p.dim() == 4]
+    s0 = state()
+    y0 = out()
+    assert torch.equal(out(), y0)                         # second call: served from the cache
+    with torch.no_grad():                                 # in-place update through torch
+        for p in convs:
+            p.mul_(1.5)
+    y1 = out()
+    assert not torch.equal(y1, y0)
+    assert torch.equal(y1, fresh(state()))
+    for p in convs:                                       # a write torch does not see, then the bump
+        p.data.mul_(0.5)
+    sf.ops.bump_weight_epoch()
+    y2 = out()
+    assert not torch.equal(y2, y1)
+    assert torch.equal(y2, fresh(state()))
+    m.load_state_dict(s0)                                 # load_state_dict copies in place
+    assert torch.equal(out(), fresh(s0))
