@@ -282,6 +282,13 @@ int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, float* dw, f
  * y f32 [N,1,OH,OW]. */
 int sf_conv_k1_fwd(const void* x, int dtype, const float* w, const float* b, float* y, int N,
                    int H, int W, int C, int Creal, int R, int pad, void* stream);
+/* sf_conv_k1_fwd with a caller-provided workspace (sf_conv_k1_fwd_workspace_bytes; 0 = the shape has
+ * no use for one and the call forwards to sf_conv_k1_fwd): for the bf16 4x4 PatchGAN head
+ * (src/model/gan.py:33) the workspace takes the per-input-pixel tap products [N*H*W][16] of an MFMA
+ * pass that reads the input once, and a second launch sums the 16 shifted products per output. */
+size_t sf_conv_k1_fwd_workspace_bytes(int dtype, int N, int H, int W, int C, int R);
+int sf_conv_k1_fwd_ws(const void* x, int dtype, const float* w, const float* b, float* y, void* ws,
+                      size_t ws_bytes, int N, int H, int W, int C, int Creal, int R, int pad, void* stream);
 /* dx NHWC dtype [N,H,W,C] = sum_taps dy * w, optionally multiplied by (aux>0) (ReLU mask) */
 int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* aux, void* dx, int dtype,
                         int N, int H, int W, int C, int Creal, int R, int pad, void* stream);

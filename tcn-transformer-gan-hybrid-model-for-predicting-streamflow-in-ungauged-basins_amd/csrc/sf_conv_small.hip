@@ -906,6 +906,139 @@ __global__ __launch_bounds__(NT) void head_bwd_data_kernel(const float* __restri
     }
 }
 
+// ---- MFMA forms of the 4x4 head for bf16 (C a multiple of 32, at most 512).
+// Forward in two steps: P[pixel][tap] = sum_c x[pixel][c] * w[c][tap] (a [M x C] x [C x 16] product
+// in which x crosses the memory system once, where the direct form re-reads every input pixel for
+// each of the 16 outputs it feeds), then y[o] = b + sum_taps P[o + tap - pad][tap].
+// Lane (n = lane & 15, q = lane >> 4) of v_mfma_f32_16x16x32_bf16: A row n, B column n, reduction
+// elements 8q .. 8q+7; D rows 4q .. 4q+3, column n.
+constexpr int HT_LD = 520;      // LDS row of one tap: 512 channels + 8 (16-lane reads spread over the banks)
+__global__ __launch_bounds__(NT) void head_taps_mfma_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ P, unsigned M, int C, int Creal) {
+    __shared__ __attribute__((aligned(16))) bf16 sw[16 * HT_LD];
+    for (int c = threadIdx.x; c < C; c += NT) {
+        float f[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) f[t] = c < Creal ? w[(size_t)c * 16 + t] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sw[t * HT_LD + c] = (bf16)f[t];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    const unsigned wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (NT / 64);
+    const unsigned ngroups = (M + 15) / 16;
+    const int ksteps = C / 32;
+    for (unsigned g = wave; g < ngroups; g += nwaves) {
+        const unsigned pix = g * 16 + n;
+        const bf16* xr = x + (size_t)(pix < M ? pix : 0) * C + 8 * q;
+        uint4 a[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            a[ks] = (ks < ksteps && pix < M) ? *reinterpret_cast<const uint4*>(xr + ks * 32) : make_uint4(0, 0, 0, 0);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks < ksteps) {      // (wave-uniform)
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sw + n * HT_LD + ks * 32 + 8 * q);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[ks]), fb, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned row = g * 16 + 4 * q + i;
+            if (row < M) P[(size_t)row * 16 + n] = acc[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void head_gather_kernel(const float* __restrict__ P, const float* __restrict__ b,
+                                                         float* __restrict__ y, unsigned total, int H, int W, int OH,
+                                                         int OW, int pad) {
+    const unsigned o = blockIdx.x * NT + threadIdx.x;
+    if (o >= total) return;
+    const unsigned q = o / (unsigned)OW, ow = o - q * OW;
+    const unsigned n = q / (unsigned)OH, oh = q - n * OH;
+    float v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int iy = (int)oh - pad + (t >> 2), ix = (int)ow - pad + (t & 3);
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float pv = P[ok ? (((size_t)n * H + iy) * W + ix) * 16 + t : 0];
+        v[t] = ok ? pv : 0.f;
+    }
+    // taps added in filter order, like the direct kernel's loop
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc += v[t];
+    y[o] = acc + b[0];
+}
+
+// Data gradient: dx[pixel][c] = sum_taps dy[pixel + pad - tap] * w[c][tap] as one 32x32x16 MFMA per
+// (32 pixels, 32 channels): A = weights (rows = channels), B = the 16 gathered output gradients of a
+// pixel (columns = pixels), so that a lane ends up with 4-channel runs of one pixel, regrouped into
+// 16-byte stores as in the 3x3 kernel's epilogue.
+__global__ __launch_bounds__(NT) void head_bwd_data_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                const bf16* __restrict__ aux, bf16* __restrict__ dx,
+                                                                unsigned M, int H, int W, int C, int Creal, int pad,
+                                                                int OH, int OW) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const unsigned wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (NT / 64);
+    const unsigned ngroups = (M + 31) / 32;
+    const int nblk = C / 32;
+    for (unsigned g = wave; g < ngroups; g += nwaves) {
+        const unsigned pix = g * 32 + r;
+        const bool live = pix < M;
+        const unsigned pc = live ? pix : 0;
+        const unsigned qq = pc / (unsigned)W, ix = pc - qq * W;
+        const unsigned n = qq / (unsigned)H, iy = qq - n * H;
+        float gv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = 8 * h + j;
+            const int oh = (int)iy + pad - (t >> 2), ow = (int)ix + pad - (t & 3);
+            const bool ok = live && oh >= 0 && oh < OH && ow >= 0 && ow < OW;
+            const float v = dy[ok ? ((size_t)n * OH + oh) * OW + ow : 0];
+            gv[j] = ok ? v : 0.f;
+        }
+        const bf16x8 fb = to_bf16x8(gv);
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int c = blk * 32 + r;
+            float wf[8];
+            const float4 w0 = *reinterpret_cast<const float4*>(w + (size_t)(c < Creal ? c : 0) * 16 + 8 * h);
+            const float4 w1 = *reinterpret_cast<const float4*>(w + (size_t)(c < Creal ? c : 0) * 16 + 8 * h + 4);
+            wf[0] = w0.x; wf[1] = w0.y; wf[2] = w0.z; wf[3] = w0.w; wf[4] = w1.x; wf[5] = w1.y; wf[6] = w1.z; wf[7] = w1.w;
+            if (c >= Creal)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wf[j] = 0.f;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(wf), fb, acc, 0, 0, 0);
+            // acc[4 g4 + e]: channel blk * 32 + 8 g4 + 4 h + e of pixel r
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const unsigned A0 = pack_bf16x2(acc[8 * gp], acc[8 * gp + 1]), A1 = pack_bf16x2(acc[8 * gp + 2], acc[8 * gp + 3]);
+                const unsigned B0 = pack_bf16x2(acc[8 * gp + 4], acc[8 * gp + 5]), B1 = pack_bf16x2(acc[8 * gp + 6], acc[8 * gp + 7]);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
+                uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                const size_t off = (size_t)pc * C + blk * 32 + 8 * (2 * gp + h);
+                if (aux) {
+                    const uint4 m = *reinterpret_cast<const uint4*>(aux + off);
+                    // bf16 > 0  <=>  sign clear and not zero
+                    auto keep = [](unsigned v, unsigned mk) {
+                        const unsigned lo = (!(mk & 0x8000u) && (mk & 0x7fffu)) ? 0xffffu : 0u;
+                        const unsigned hi = (!(mk & 0x80000000u) && (mk & 0x7fff0000u)) ? 0xffff0000u : 0u;
+                        return v & (lo | hi);
+                    };
+                    o.x = keep(o.x, m.x); o.y = keep(o.y, m.y); o.z = keep(o.z, m.z); o.w = keep(o.w, m.w);
+                }
+                if (live) *reinterpret_cast<uint4*>(dx + off) = o;
+            }
+        }
+    }
+}
+
 // dw[c][t] = sum over INPUT pixels of x[pixel][c] * dy[pixel + pad - tap t]: a thread owns one
 // channel chunk, loads each input chunk once and applies all RS taps to it (the dy values are
 // scalars from a tiny tensor), so x crosses the memory system once.
@@ -1043,6 +1176,11 @@ inline bool head_ok(int dtype, int C, int R, long long items) {
     const int g = C / (dtype == SF_BF16 ? 8 : 4);
     return R >= 1 && R <= 4 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 && R * R * C <= HEAD_MAX_W && g * R * R <= 1024 &&
            (g * R * R) % 64 == 0 && items < 0x7fffffffLL;
+}
+
+// the MFMA forms of the 4x4 head: bf16, channel count a multiple of 32 up to 512
+inline bool head_mfma_ok(int dtype, int C, int R, long long items) {
+    return dtype == SF_BF16 && R == 4 && C % 32 == 0 && C >= 32 && C <= 512 && items < 0x7fffffffLL / 16;
 }
 
 struct RowSplit { unsigned per; int grid; };
@@ -1209,6 +1347,30 @@ extern "C" int sf_conv_k1_fwd(const void* x, int dtype, const float* w, const fl
     return SF_OK;
 }
 
+extern "C" size_t sf_conv_k1_fwd_workspace_bytes(int dtype, int N, int H, int W, int C, int R) {
+    const long long M = (long long)N * H * W;
+    return head_mfma_ok(dtype, C, R, M) ? (size_t)M * 16 * sizeof(float) : 0;
+}
+
+extern "C" int sf_conv_k1_fwd_ws(const void* x, int dtype, const float* w, const float* b, float* y, void* ws,
+                                 size_t ws_bytes, int N, int H, int W, int C, int Creal, int R, int pad, void* stream) {
+    SF_REQUIRE(x && w && b && y, "sf_conv_k1_fwd_ws: null argument");
+    int OH, OW;
+    if (int rc = k1_dims("sf_conv_k1_fwd_ws", dtype, N, H, W, C, Creal, R, pad, &OH, &OW)) return rc;
+    const size_t need = sf_conv_k1_fwd_workspace_bytes(dtype, N, H, W, C, R);
+    if (need == 0) return sf_conv_k1_fwd(x, dtype, w, b, y, N, H, W, C, Creal, R, pad, stream);
+    SF_REQUIRE(ws && ws_bytes >= need, "sf_conv_k1_fwd_ws: workspace of %zu bytes, %zu needed", ws_bytes, need);
+    const unsigned M = (unsigned)((long long)N * H * W);
+    const long long total = (long long)N * OH * OW;
+    long long grid = (((long long)M + 15) / 16 + NT / 64 - 1) / (NT / 64); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(head_taps_mfma_kernel, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, w,
+                       (float*)ws, M, C, Creal);
+    hipLaunchKernelGGL(head_gather_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream,
+                       (const float*)ws, b, y, (unsigned)total, H, W, OH, OW, pad);
+    SF_LAUNCH_CHECK("sf_conv_k1_fwd_ws");
+    return SF_OK;
+}
+
 extern "C" int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* aux, void* dx, int dtype, int N, int H,
                                    int W, int C, int Creal, int R, int pad, void* stream) {
     SF_REQUIRE(dy && w && dx, "sf_conv_k1_bwd_data: null argument");
@@ -1220,6 +1382,14 @@ extern "C" int sf_conv_k1_bwd_data(const float* dy, const float* w, const void* 
         const RowSplit sp = split_rows_small(M, (NT / (C / epc)) * 8, 4096);
         DISPATCH_T(dtype, hipLaunchKernelGGL(pw1_bwd_data_kernel<T>, dim3(sp.grid), dim3(NT), 0, (hipStream_t)stream, dy,
                                              w, (const T*)aux, (T*)dx, (unsigned)M, sp.per, C, Creal));
+        SF_LAUNCH_CHECK("sf_conv_k1_bwd_data");
+        return SF_OK;
+    }
+    if (head_mfma_ok(dtype, C, R, (long long)N * H * W)) {
+        const long long items = (long long)N * H * W;
+        long long grid = ((items + 31) / 32 + NT / 64 - 1) / (NT / 64); if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(head_bwd_data_mfma_kernel, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)stream, dy, w,
+                           (const bf16*)aux, (bf16*)dx, (unsigned)items, H, W, C, Creal, pad, OH, OW);
         SF_LAUNCH_CHECK("sf_conv_k1_bwd_data");
         return SF_OK;
     }

@@ -60,6 +60,7 @@ def lib():
         L.sf_conv3x3_staged_weight_bytes.restype = ctypes.c_size_t
         L.sf_conv4x4s2_staged_weight_bytes.restype = ctypes.c_size_t
         L.sf_wgrad4x4s2_workspace_bytes.restype = ctypes.c_size_t
+        L.sf_conv_k1_fwd_workspace_bytes.restype = ctypes.c_size_t
         L.sf_enc1_bwd_workspace_bytes.restype = ctypes.c_size_t
         L.sf_date_image_metrics_workspace_bytes.restype = ctypes.c_size_t
         L.sf_gru_save_floats.restype = ctypes.c_size_t
@@ -72,7 +73,7 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
-           "sf_conv_k1_fwd", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
+           "sf_conv_k1_fwd", "sf_conv_k1_fwd_ws", "sf_conv_k1_fwd_workspace_bytes", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss", "sf_image_station_loss_static",
            "sf_bce_logits", "sf_adam", "sf_adam_begin", "sf_adam_guarded", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
@@ -749,6 +750,12 @@ def conv_k1_fwd(x, w, b, R, pad):
     Creal = w.shape[1]
     OH, OW = H + 2 * pad - R + 1, W + 2 * pad - R + 1
     y = torch.empty((N, 1, OH, OW), device=x.device, dtype=torch.float32)
+    nbytes = int(lib().sf_conv_k1_fwd_workspace_bytes(code_of(x.dtype), N, H, W, C, R))
+    if nbytes:
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        _check(lib().sf_conv_k1_fwd_ws(_p(x), code_of(x.dtype), _p(w), _p(b), _p(y), _p(ws), ctypes.c_size_t(nbytes), N, H, W,
+                                       C, Creal, R, pad, _stream()), "sf_conv_k1_fwd_ws")
+        return y
     _check(lib().sf_conv_k1_fwd(_p(x), code_of(x.dtype), _p(w), _p(b), _p(y), N, H, W, C, Creal, R, pad, _stream()),
            "sf_conv_k1_fwd")
     return y

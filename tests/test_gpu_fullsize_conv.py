@@ -233,3 +233,30 @@ def test_full_size_wgrad_with_tile_stealing(sf):
         again = torch.empty(K, C, 3, 3, device=DEV)
         ops.wgrad3x3(x, dz, again)
         assert torch.equal(again, ref)      # fixed slices: bit-reproducible
+
+
+def test_full_size_patchgan_head(sf):
+    """The 4x4 one-channel head at the benchmark shape (32 x 25 x 25 x 512, bf16) on its MFMA kernels
+    (tap products + shifted sum; data gradient as a 16-deep product) and at a ragged shape, against
+    f32 torch: forward, data gradient with and without the ReLU mask, weight and bias gradient
+    (stated bf16 tolerance: 1e-2 of the tensor's maximum)."""
+    ops = sf.ops
+    for (N, H, W, C) in ((32, 25, 25, 512), (3, 7, 9, 64)):
+        torch.manual_seed(17)
+        x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+        w = torch.randn(1, C, 4, 4, device=DEV) * 0.02
+        b = torch.randn(1, device=DEV)
+        y = ops.conv_k1_fwd(x, w, b, 4, 1)
+        xg = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        wg = w.clone().requires_grad_(True)
+        bg = b.clone().requires_grad_(True)
+        ref = torch.nn.functional.conv2d(xg, wg, bg, padding=1)
+        assert _rel(y.reshape(ref.shape), ref.detach()) <= 1e-2
+        dy = torch.randn_like(ref)
+        ref.backward(dy)
+        dx = ops.conv_k1_bwd_data(dy.reshape(y.shape).contiguous(), w, x, 4, 1, relu_mask=False)
+        assert _rel(dx.float().permute(0, 3, 1, 2), xg.grad) <= 1e-2
+        dxm = ops.conv_k1_bwd_data(dy.reshape(y.shape).contiguous(), w, x, 4, 1, relu_mask=True)
+        assert _rel(dxm.float().permute(0, 3, 1, 2), xg.grad * (xg.detach() > 0)) <= 1e-2
+        dw, db = ops.conv_k1_bwd_weight(x, dy.reshape(y.shape).contiguous(), C, 4, 1)
+        assert _rel(dw, wg.grad) <= 1e-2 and _rel(db.reshape(-1), bg.grad) <= 1e-2

@@ -30,4 +30,11 @@ timed("fwd", lambda: ops.conv_k1_fwd(x, w, b, 4, 1))
 timed("bwd_data", lambda: ops.conv_k1_bwd_data(dy, w, x, 4, 1, relu_mask=False))
 timed("bwd_weight", lambda: ops.conv_k1_bwd_weight(x, dy, C, 4, 1))
 ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w, b, padding=1)
+xg = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+torch.nn.functional.conv2d(xg, w, b, padding=1).backward(dy.reshape(ref.shape))
+dx = ops.conv_k1_bwd_data(dy, w, x, 4, 1, relu_mask=False)
+print("bwd_data err", float((dx.float().permute(0, 3, 1, 2) - xg.grad).abs().max() / xg.grad.abs().max()))
+dxm = ops.conv_k1_bwd_data(dy, w, x, 4, 1, relu_mask=True)
+want = xg.grad * (x.float().permute(0, 3, 1, 2) > 0)
+print("bwd_data masked err", float((dxm.float().permute(0, 3, 1, 2) - want).abs().max() / want.abs().max()))
 print("fwd err", float((y.reshape(ref.shape) - ref).abs().max() / ref.abs().max()))
