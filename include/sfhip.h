@@ -89,6 +89,16 @@ int sf_gemm(const sf_gemm_desc* d, const void* A, const void* B, const float* bi
 int sf_gemm_batch(int n, const sf_gemm_desc* d, const void* const* A, const void* const* B,
                   const float* const* bias, const void* const* aux, void* const* out, void* stream);
 
+/* sf_conv3x3 that also writes dot_out[pixel] = dot_b[0] + sum_k dot_w[k] * out[pixel][k] (f32, one
+ * value per pixel, from the values as stored in bf16): the decoder's ReLU -> 1x1 output conv
+ * (src/model/decoder.py:152,175) folded into conv2's epilogue, so that conv2's output is written
+ * for the backward pass but not read back.  Only for shapes that run on the kernel with resident
+ * weights (sf_conv3x3_dot_ok: C = 64, K <= 64 in 8-channel groups, bf16 output); dot_w holds K floats. */
+int sf_conv3x3_dot_ok(int C, int K, int ldo, int out_dtype);
+int sf_conv3x3_dot(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N,
+                   int H, int W, int C, int K, int ldo, const int* dy, const int* dx, int act, int aux_mode,
+                   int out_dtype, const float* dot_w, const float* dot_b, float* dot_out, void* stream);
+
 /*
  * 3x3 stride-1 convolution, bf16 NHWC, forward or data gradient (nn.Conv2d(k=3,p=1) at
  * src/model/cnn_encoder.py:45-51 and src/model/decoder.py:148-150): the (TH+2)x(TW+2) halo

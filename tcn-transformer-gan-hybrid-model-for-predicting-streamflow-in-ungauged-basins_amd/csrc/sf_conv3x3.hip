@@ -30,6 +30,8 @@ struct C3Params {
     int act, aux_mode, out_dtype;
     int dy[9], dx[9];
     int wstaged;
+    // optional 1x1 projection of the finished output row to one channel (the resident shape only)
+    const float* dot_w = nullptr; const float* dot_b = nullptr; float* dot_out = nullptr;
 };
 
 __device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
@@ -281,6 +283,8 @@ struct C3DParams {
     int dy[9], dx[9];
     int wstaged;     // weights given as the stages' LDS images (sf_conv3x3_stage_weights): contiguous 1 KiB copy pieces
     int qslot;       // work-queue slot of this launch, -1: items dealt statically
+    // resident shape, K <= 64: dot_out[pixel] = dot_b[0] + sum_k dot_w[k] * out[pixel][k] (the values as stored)
+    const float* dot_w; const float* dot_b; float* dot_out;
 };
 
 struct ItemPos {
@@ -491,13 +495,14 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // pixel, with streaming (non-temporal) stores: the output then neither leaves partial lines for L2
     // to merge nor pushes the input lines of the next stages out of it.
     auto epilogue = [&](const ItemPos& it, char* lines) {
-        long long pixoff[2];
+        long long pixoff[2], pixidx[2];
         bool pv[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int gy = it.y0 + (lyx[c] >> 16), gx = it.x0 + (lyx[c] & 0xffff);
             pv[c] = pin[c] && gy < p.H && gx < p.W;
-            pixoff[c] = pv[c] ? (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo : 0;
+            pixidx[c] = pv[c] ? ((long long)it.n * p.H + gy) * p.W + gx : 0;
+            pixoff[c] = pixidx[c] * p.ldo;
         }
         auto pack2 = [](float x, float y) {
             typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -571,6 +576,8 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                     v[2] = p2 ? v[2] : neg * v[2]; v[3] = p3 ? v[3] : neg * v[3];
                 }
             };
+            const bool dot = RES && p.dot_out != nullptr;      // (host: bf16 output in 16-byte groups, k0 = 0)
+            float dsum = 0.f;
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -581,6 +588,16 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                     if (wide_out) {
                         const unsigned A0 = pack2(v0[0], v0[1]), A1 = pack2(v0[2], v0[3]);
                         const unsigned B0 = pack2(v1[0], v1[1]), B1 = pack2(v1[2], v1[3]);
+                        if (RES && dot) {
+                            // the projection reads what a separate pass would read back: the rounded values
+                            const float* dw = sbias + D_BIAS_MAX + a * 32 + 4 * h;
+                            const float4 w0 = *reinterpret_cast<const float4*>(dw + 16 * gp);
+                            const float4 w1 = *reinterpret_cast<const float4*>(dw + 16 * gp + 8);
+                            dsum += w0.x * __uint_as_float(A0 << 16) + w0.y * __uint_as_float(A0 & 0xffff0000u) +
+                                    w0.z * __uint_as_float(A1 << 16) + w0.w * __uint_as_float(A1 & 0xffff0000u) +
+                                    w1.x * __uint_as_float(B0 << 16) + w1.y * __uint_as_float(B0 & 0xffff0000u) +
+                                    w1.z * __uint_as_float(B1 << 16) + w1.w * __uint_as_float(B1 & 0xffff0000u);
+                        }
                         const auto s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
                         const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
@@ -611,6 +628,10 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                         }
                     }
                 }
+            if (RES && dot && wide_out) {
+                dsum += __shfl_xor(dsum, 32, 64);        // the other 32 channels of the pixel
+                if (h == 0 && pv[c]) p.dot_out[pixidx[c]] = dsum + p.dot_b[0];
+            }
             if (RES && lines && wide_out) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -640,6 +661,8 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         float* sb = reinterpret_cast<float*>(smd + 2 * D_BUF);
         for (int i = tid; i < D_BIAS_MAX; i += D_NT) sb[i] = i < p.K ? p.bias[i] : 0.f;
     }
+    if (RES && p.dot_out && tid < 64)
+        reinterpret_cast<float*>(smd + 2 * D_BUF)[D_BIAS_MAX + tid] = tid < p.K ? p.dot_w[tid] : 0.f;
     // whole-line streaming stores: bf16 output rows of exactly 64 channels (one 128-byte line each)
     const bool line_stores = RES && p.K == 64 && p.ldo == 64 && p.out_dtype == SF_BF16 &&
                              (reinterpret_cast<uintptr_t>(p.out) & 127) == 0;
@@ -770,6 +793,7 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
     p.in = q.in; p.w = q.w; p.bias = q.bias; p.aux = q.aux; p.out = q.out;
     p.N = q.N; p.H = q.H; p.W = q.W; p.C = q.C; p.K = q.K; p.ldo = q.ldo;
     p.act = q.act; p.aux_mode = q.aux_mode; p.out_dtype = q.out_dtype; p.wstaged = q.wstaged;
+    p.dot_w = q.dot_w; p.dot_b = q.dot_b; p.dot_out = q.dot_out;
     for (int t = 0; t < 9; ++t) { p.dy[t] = q.dy[t]; p.dx[t] = q.dx[t]; }
     pick_tile_dma(p.H, p.W, &p.TH, &p.TW);
     p.tiles_x = (p.W + p.TW - 1) / p.TW;
@@ -783,7 +807,7 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
     p.ntiles = (int)ntiles;
     p.ktiles = (p.K + KT - 1) / KT;
     p.nchunks = (p.C + CK - 1) / CK;
-    const size_t lds = 2 * (size_t)Cf::BUF + sizeof(float) * D_BIAS_MAX;
+    const size_t lds = 2 * (size_t)Cf::BUF + sizeof(float) * D_BIAS_MAX + (RES ? sizeof(float) * 64 : 0);
     void (*kern)(C3DParams) = RES ? &conv3_dma_res_kernel : KT == 64 ? &conv3_dma_kernel : &conv3_dma_wide_kernel;
     static DeviceOnce attr_set;
     if (!attr_set.done()) {
@@ -882,9 +906,35 @@ extern "C" int sf_conv3x3_stage_weights(const void* wp, void* out, int C, int K,
     return SF_OK;
 }
 
+static int conv3x3_call(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N, int H,
+                        int W, int C, int K, int ldo, const int* dy, const int* dx, int act, int aux_mode,
+                        int out_dtype, int w_staged, const float* dot_w, const float* dot_b, float* dot_out,
+                        void* stream);
+
 extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N, int H,
                           int W, int C, int K, int ldo, const int* dy, const int* dx, int act, int aux_mode,
                           int out_dtype, int w_staged, void* stream) {
+    return conv3x3_call(in, wp, bias, aux, out, N, H, W, C, K, ldo, dy, dx, act, aux_mode, out_dtype, w_staged, nullptr,
+                        nullptr, nullptr, stream);
+}
+
+extern "C" int sf_conv3x3_dot_ok(int C, int K, int ldo, int out_dtype) {
+    return conv3_variant(C, K) == 1 && K % 8 == 0 && ldo % 8 == 0 && out_dtype == SF_BF16;
+}
+
+extern "C" int sf_conv3x3_dot(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N,
+                              int H, int W, int C, int K, int ldo, const int* dy, const int* dx, int act, int aux_mode,
+                              int out_dtype, const float* dot_w, const float* dot_b, float* dot_out, void* stream) {
+    SF_REQUIRE(dot_w && dot_b && dot_out, "sf_conv3x3_dot: null projection argument");
+    SF_REQUIRE(sf_conv3x3_dot_ok(C, K, ldo, out_dtype), "sf_conv3x3_dot: shape C=%d K=%d ldo=%d does not run on the resident-weight kernel", C, K, ldo);
+    return conv3x3_call(in, wp, bias, aux, out, N, H, W, C, K, ldo, dy, dx, act, aux_mode, out_dtype, 0, dot_w, dot_b,
+                        dot_out, stream);
+}
+
+static int conv3x3_call(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N, int H,
+                        int W, int C, int K, int ldo, const int* dy, const int* dx, int act, int aux_mode,
+                        int out_dtype, int w_staged, const float* dot_w, const float* dot_b, float* dot_out,
+                        void* stream) {
     SF_REQUIRE(in && wp && out && dy && dx, "sf_conv3x3: null argument");
     SF_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "sf_conv3x3: bad shape");
     SF_REQUIRE(C % 16 == 0, "sf_conv3x3: C=%d must be a multiple of 16", C);
@@ -896,6 +946,7 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
     p.in = (const bf16*)in; p.w = (const bf16*)wp; p.bias = bias; p.aux = (const bf16*)aux; p.out = out;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.ldo = ldo;
     p.act = act; p.aux_mode = aux_mode; p.out_dtype = out_dtype; p.wstaged = w_staged ? 1 : 0;
+    p.dot_w = dot_w; p.dot_b = dot_b; p.dot_out = dot_out;
     SF_REQUIRE(!w_staged || conv3_variant(C, K) == 0, "sf_conv3x3: staged weights given for a shape that does not take them");
     for (int t = 0; t < 9; ++t) {
         SF_REQUIRE(dy[t] >= -1 && dy[t] <= 1 && dx[t] >= -1 && dx[t] <= 1, "sf_conv3x3: tap offsets must lie in [-1, 1]");

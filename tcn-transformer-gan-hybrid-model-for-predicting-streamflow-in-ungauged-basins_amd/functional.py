@@ -324,9 +324,16 @@ class DecoderFn(torch.autograd.Function):
                           lambda: ops.pack_conv_weight(w2.detach().contiguous(), cdtype, list(range(9)), False, Hp, Hp))
         bp2 = _pad_vec(b2.detach(), Hp)
         h2 = torch.empty((B, OH, OW, Hp), device=x.device, dtype=cdtype)
-        ops.conv3x3(h1, w2p, h2, Hp, bias=bp2, act=ops.ACT_RELU, flop_c=Hc, flop_k=Hc)
         w3c = w3.detach().contiguous()
-        y = ops.conv_k1_fwd(h2, w3c, b3.detach().contiguous(), 1, 0)
+        if ops.conv3x3_dot_ok(h1, Hp, h2):
+            # the 1x1 output conv (src/model/decoder.py:152,175) rides in conv2's epilogue: h2 is written
+            # for the backward but not read back
+            y = torch.empty((B, 1, OH, OW), device=x.device, dtype=torch.float32)
+            ops.conv3x3(h1, w2p, h2, Hp, bias=bp2, act=ops.ACT_RELU, flop_c=Hc, flop_k=Hc,
+                        dot=(_pad_vec(w3c.reshape(-1), Hp), b3.detach().contiguous(), y))
+        else:
+            ops.conv3x3(h1, w2p, h2, Hp, bias=bp2, act=ops.ACT_RELU, flop_c=Hc, flop_k=Hc)
+            y = ops.conv_k1_fwd(h2, w3c, b3.detach().contiguous(), 1, 0)
         ctx.save_for_backward(src, h1, h2, w3c, w9T)
         ctx.weights = (w1, w2)
         ctx.dims = (B, C, h, w, OH, OW, Hc, Hp, cdtype)

@@ -69,7 +69,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
@@ -233,12 +233,22 @@ def conv_fprop_batch(problems):
     _check(lib().sf_gemm_batch(n, descs, A, B, None, X if any_aux else None, O, _stream()), "sf_gemm_batch")
 
 
+def conv3x3_dot_ok(x, K: int, out) -> bool:
+    """Whether conv3x3 can also emit the 1x1 projection of its output to one channel (`dot=`): the
+    shape has to run on the kernel that keeps its weights resident in LDS."""
+    return (x.dtype == torch.bfloat16 and not FORCE_GENERIC_CONV and FUSE_OUTPUT_CONV and
+            bool(lib().sf_conv3x3_dot_ok(x.shape[-1], K, out.shape[-1], code_of(out.dtype))))
+
+
 def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, aux=None, aux_mode=0, tag=None,
-            flop_c: Optional[int] = None, flop_k: Optional[int] = None):
+            flop_c: Optional[int] = None, flop_k: Optional[int] = None, dot=None):
     """3x3 stride-1 pad-1 conv (dgrad=False) or its data gradient (dgrad=True; wp packed
     transposed).  bf16 tensors with C % 16 == 0 take the LDS-patch kernel, everything else the
-    generic implicit GEMM."""
+    generic implicit GEMM.  dot = (w f32 [K], b f32 [1], y f32 [N,1,H,W]): y = b + sum_k w[k] *
+    out[..., k] from the epilogue (only where conv3x3_dot_ok says so)."""
     N, H, W, C = x.shape
+    if dot is not None and not conv3x3_dot_ok(x, K, out):
+        raise RuntimeError("conv3x3: this shape cannot fuse the output projection")
     if dgrad:
         taps = [(1 - r, 1 - s) for r in range(3) for s in range(3)]
     else:
@@ -257,8 +267,17 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
         dy = (_c_int * 9)(*[t[0] for t in taps])
         dx = (_c_int * 9)(*[t[1] for t in taps])
         staged = getattr(wp, "_sf_staged", False)
-        _check(lib().sf_conv3x3(_p(x), _p(wp), _p(bias), _p(aux), _p(out), N, H, W, C, K, out.shape[-1], dy, dx, act,
-                                aux_mode, code_of(out.dtype), int(staged), _stream()), "sf_conv3x3")
+        if dot is not None:
+            dw_, db_, dout_ = dot
+            _dev(dw_, db_, dout_, dtypes=[torch.float32, torch.float32, torch.float32])
+            if dw_.numel() != K or dout_.numel() != N * H * W:
+                raise RuntimeError("conv3x3: projection operands do not match the conv's shape")
+            _check(lib().sf_conv3x3_dot(_p(x), _p(wp), _p(bias), _p(aux), _p(out), N, H, W, C, K, out.shape[-1], dy, dx,
+                                        act, aux_mode, code_of(out.dtype), _p(dw_), _p(db_), _p(dout_), _stream()),
+                   "sf_conv3x3_dot")
+        else:
+            _check(lib().sf_conv3x3(_p(x), _p(wp), _p(bias), _p(aux), _p(out), N, H, W, C, K, out.shape[-1], dy, dx, act,
+                                    aux_mode, code_of(out.dtype), int(staged), _stream()), "sf_conv3x3")
         if rec is not None:
             e1.record()
             # algorithmic flops: real (unpadded) channel counts when the caller states them
@@ -342,6 +361,7 @@ def conv3x3_stage_weights(wp: torch.Tensor, C: int, K: int) -> torch.Tensor:
 
 
 STAGE_CONV_WEIGHTS = os.environ.get("SF_STAGE_CONV_WEIGHTS", "1") != "0"   # debug switch for A/B timing
+FUSE_OUTPUT_CONV = os.environ.get("SF_FUSE_OUTPUT_CONV", "1") != "0"       # debug switch for A/B timing
 
 
 _UPLOAD_STREAMS: dict = {}
