@@ -509,19 +509,29 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # Adam kernel together with the parameter, so the bf16 kernels need no 134 MB cast per call.  A
 # shadow counts as current while the parameter has not been written through torch since (its
 # version counter) and still lives at the same address.
-WEIGHT_EPOCH = 0     # bumped whenever an optimiser kernel rewrites parameters behind torch's back
+WEIGHT_EPOCH = 0     # bumped when parameters were rewritten behind torch's back and nobody kept track of which
 
 
 def bump_weight_epoch():
+    """Everything derived from any parameter is stale (after a write torch cannot see, e.g. through
+    `.data`, when the caller does not know or care which parameters it touched)."""
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
+
+
+def touch(params):
+    """These parameters were rewritten behind torch's back (an optimiser kernel): whatever is derived
+    from them is stale, the copies derived from other parameters stay valid."""
+    for p in params:
+        p.__dict__["_sf_epoch"] = p.__dict__.get("_sf_epoch", 0) + 1
 
 
 def derived(owner: torch.Tensor, key, build):
     """A tensor computed from parameter `owner` alone (a packed / staged copy of a conv weight),
     kept on the parameter object until the parameter changes: in place through torch (its version
-    counter), behind torch's back by an optimiser kernel (WEIGHT_EPOCH), or by moving elsewhere."""
-    ver = (WEIGHT_EPOCH, owner._version, owner.data_ptr())
+    counter), behind torch's back by an optimiser kernel (touch / bump_weight_epoch), or by moving
+    elsewhere."""
+    ver = (WEIGHT_EPOCH, owner.__dict__.get("_sf_epoch", 0), owner._version, owner.data_ptr())
     cache = owner.__dict__.setdefault("_sf_derived", {})
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:

@@ -144,7 +144,7 @@ class FlatAdam:
                 self._seen[i] += 1
             else:
                 self._uniform = False
-        ops.bump_weight_epoch()
+        ops.touch(p for p in self.params if p.grad is not None)   # only this network's packed weights go stale
 
     def grads(self) -> List[torch.Tensor]:
         """The tensors an Inf/NaN check of this step's gradients has to look at (after gather())."""

@@ -1,6 +1,6 @@
 """Packed / staged conv weights are cached on the parameter (ops.derived): the cache must follow every
 way a parameter changes -- an in-place torch update (version counter), an optimiser kernel writing
-behind torch's back (ops.WEIGHT_EPOCH) and load_state_dict -- and a write through `.data`, which
+behind torch's back (ops.touch, from FlatAdam.step) and load_state_dict -- and a write through `.data`, which
 torch does not count, after ops.bump_weight_epoch()."""
 import pytest
 import torch
