@@ -156,18 +156,9 @@ __global__ __launch_bounds__(E_NT, 3) void enc1_kernel(E1Params p) {
                 fa[tap] = *reinterpret_cast<const bf16x8*>(sP + (tap / 3 == 1 ? a_off1 : a_off0) + ((2 * rt + tap / 3) * E_PW + tap % 3) * E_ROWB);
             // validity of the lane's 16 pixels: register i -> window 2 (i >> 2) + h, position i & 3
             const int gy0 = cur.y0 + 2 * rt;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                // keeps the weight reads of later channel tiles from being hoisted up here (registers)
-                __builtin_amdgcn_sched_barrier(0);
-                f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + b_off + (tap * p.K + kt * 32) * E_ROWB);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap], fb, acc, 0, 0, 0);
-                }
+            // two channel tiles at a time: their MFMA chains (nine dependent MFMAs each) alternate, so that
+            // one chain's result latency is covered by the other's issue
+            auto finish_tile = [&](int kt, const f32x16& acc) __attribute__((always_inline)) {
                 // tiles inside the image skip the validity tests (wave-uniform branch)
                 if (MODE == E_STATS) {
                     float s = 0.f, q2 = 0.f;
@@ -205,6 +196,23 @@ __global__ __launch_bounds__(E_NT, 3) void enc1_kernel(E1Params p) {
                         if (full || (wy < PH && wx < PWd)) yrow[(size_t)2 * g * p.K] = (bf16)mx;
                     }
                 }
+            };
+#pragma unroll
+            for (int kt = 0; kt < NKT; kt += 2) {
+                // keeps the weight reads of later channel tiles from being hoisted up here (registers)
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(sW + b_off + (tap * p.K + kt * 32) * E_ROWB);
+                    const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(sW + b_off + (tap * p.K + (kt + 1) * 32) * E_ROWB);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap], fb0, acc0, 0, 0, 0);
+                    if (kt + 1 < NKT) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap], fb1, acc1, 0, 0, 0);
+                }
+                finish_tile(kt, acc0);
+                if (kt + 1 < NKT) finish_tile(kt + 1, acc1);
             }
         }
     }
