@@ -337,8 +337,15 @@ class Trainer:
         d_batch = self.use_gan and bi % self.d_update_interval == 0
         self._reduce_now = self.distributed and stepping
         d_live = self._d_grads_consumed(bi)
+        # The reference's generator backward also leaves gradients in the discriminator's parameters
+        # (D(pred) is part of loss_G's graph, src/train.py:212-228), which its optimizer_D then applies
+        # together with those of loss_D.  The discriminator's backward is linear in the gradient it is
+        # fed, and D(pred.detach()) below replays the very same activations, so on a discriminator batch
+        # that contribution is added to loss_D's backward as gan_weight * BCE(D(pred.detach()), 1)
+        # instead: one pass of weight-gradient kernels over the fake branch, not two.
+        merge_d = d_batch and d_live
         if self.use_gan:
-            self._set_d_requires_grad(d_live)
+            self._set_d_requires_grad(d_live and not merge_d)
         images = images.to(self.device, non_blocking=True)
         output_image = output_image.to(self.device, non_blocking=True)
         ops.nan_inf_flag(images.contiguous().float().view(-1), self.nan_flags[_FLAG_IMAGES:_FLAG_IMAGES + 1])
@@ -370,6 +377,7 @@ class Trainer:
                 self._wait_reduces()
             self._step(self.opt_g, scale, 0)
         if d_batch:
+            self._set_d_requires_grad(d_live)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp), torch.set_grad_enabled(d_live):
                 pred_real = self.discriminator(output_image)
                 # D(pred.detach()) repeats D(pred) of the generator loss above (same input, same
@@ -377,8 +385,11 @@ class Trainer:
                 pred_fake_d = self.discriminator(pred.detach(), reuse=fake_record)
                 loss_d = self.gan_loss_fn.discriminator_loss(pred_real, pred_fake_d)
                 ld["gan_d"] = loss_d
+                back_d = loss_d
+                if merge_d:
+                    back_d = loss_d + self.gan_weight * self.gan_loss_fn.gan_loss(pred_fake_d, torch.ones(1, device=self.device))
             if d_live:
-                (loss_d / self.accum).backward()
+                (back_d / self.accum).backward()
         if stepping:
             if d_batch:
                 self.opt_d.gather()
