@@ -166,6 +166,9 @@ int sf_wgrad4x4s2(const void* x, const void* dout, float* dw, float* ws, size_t 
 /* NCHW f32 -> NHWC (dtype) with channels zero-padded to Cpad. (images.view at src/model/__init__.py:125) */
 int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad,
                     void* stream);
+/* the same layout change for a bf16 NCHW source (the gradient that arrives at the encoder from the
+ * bf16 Linear layer): bf16 [N,C,H,W] -> bf16 [N,H,W,Cpad], Cpad >= 64 */
+int sf_nchw_bf16_to_nhwc(const void* in, void* out, int N, int C, int H, int W, int Cpad, void* stream);
 /* NHWC (dtype, Cpad) -> NCHW f32 (first C channels). */
 int sf_nhwc_to_nchw(const void* in, int dtype, float* out, int N, int C, int H, int W, int Cpad,
                     void* stream);

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(NT) void nchw_to_nhwc_px4_kernel(const float* __res
 
 // Many channels: a workgroup transposes a tile of 64 pixels x 64 channels through LDS, so that
 // both the channel-plane reads (256-byte runs) and the pixel-row writes (128-byte runs) coalesce.
-template <typename T>
-__global__ __launch_bounds__(NT) void nchw_to_nhwc_tile_kernel(const float* __restrict__ in, T* __restrict__ out, int C,
+template <typename T, typename TI = float>
+__global__ __launch_bounds__(NT) void nchw_to_nhwc_tile_kernel(const TI* __restrict__ in, T* __restrict__ out, int C,
                                                                int HW, int Cpad, int ptiles, int ctiles) {
     constexpr int EPC = ElemTraits<T>::EPC;
     __shared__ float sm[64][65];
@@ -98,12 +98,12 @@ __global__ __launch_bounds__(NT) void nchw_to_nhwc_tile_kernel(const float* __re
     {
         const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;
         const bool pok = p0 + px < HW;
-        const float* src = in + ((size_t)n * C + c0) * HW + p0 + (pok ? px : 0);
+        const TI* src = in + ((size_t)n * C + c0) * HW + p0 + (pok ? px : 0);
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ch = cq * 16 + i;
-            v[i] = src[(size_t)(c0 + ch < C ? ch : 0) * HW];
+            v[i] = (float)src[(size_t)(c0 + ch < C ? ch : 0) * HW];
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -456,6 +456,19 @@ __global__ void bilinear_bwd_y_kernel(const float* __restrict__ tmp, float* __re
     if ((dtype) == SF_BF16) { using T = bf16; CALL; }                 \
     else if ((dtype) == SF_F32) { using T = float; CALL; }            \
     else { sf_set_error("bad dtype %d", (int)(dtype)); return SF_EINVAL; }
+
+extern "C" int sf_nchw_bf16_to_nhwc(const void* in, void* out, int N, int C, int H, int W, int Cpad, void* stream) {
+    SF_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "sf_nchw_bf16_to_nhwc: bad arguments");
+    SF_REQUIRE(Cpad % 8 == 0 && Cpad >= 64, "sf_nchw_bf16_to_nhwc: Cpad=%d must be a multiple of 8, at least 64", Cpad);
+    const int HWi = H * W;
+    const int ptiles = (HWi + 63) / 64, ctiles = (Cpad + 63) / 64;
+    const long long blocks = (long long)N * ptiles * ctiles;
+    SF_REQUIRE(blocks < 0x7fffffffLL, "sf_nchw_bf16_to_nhwc: tensor too large");
+    hipLaunchKernelGGL((nchw_to_nhwc_tile_kernel<bf16, bf16>), dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16*)in, (bf16*)out, C, HWi, Cpad, ptiles, ctiles);
+    SF_LAUNCH_CHECK("sf_nchw_bf16_to_nhwc");
+    return SF_OK;
+}
 
 extern "C" int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad,
                                void* stream) {

@@ -101,7 +101,8 @@ class EncoderFn(torch.autograd.Function):
                 h, w = h // 2, w // 2
             else:
                 oh, ow = (target, target) if (h != target or w != target) else (h, w)
-                out = ops.bn_relu_avgpool_fwd(z, st, K, oh, ow, torch.float32)
+                # bf16 mode: the feature map leaves in bf16 (what the Linear layer behind it rounds to anyway)
+                out = ops.bn_relu_avgpool_fwd(z, st, K, oh, ow, cdtype if cdtype == torch.bfloat16 else torch.float32)
         ctx.saved = saved
         ctx.params = params
         ctx.training = training
@@ -116,7 +117,7 @@ class EncoderFn(torch.autograd.Function):
         N, Cin, H, W = ctx.in_shape
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         K_last = params[5 * (L - 1)].shape[0]
-        dy = ops.nchw_to_nhwc(dout.contiguous().float(), cdtype, ops.roundup(K_last, 8))
+        dy = ops.nchw_to_nhwc(dout.contiguous(), cdtype, ops.roundup(K_last, 8))
         oh, ow = dout.shape[-2], dout.shape[-1]
         dx = None
         for l in range(L - 1, -1, -1):
@@ -147,18 +148,19 @@ class EncoderFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------ 262144-wide Linear
-def _split_gemm(A, B, I, J, R, lda, ldb, ldo, a_km, nsplit, bias):
+def _split_gemm(A, B, I, J, R, lda, ldb, ldo, a_km, nsplit, bias, out_dtype=torch.float32):
     """out f32 [J][I] = B[J][R] . A^T (+ bias) with the reduction split over nsplit workgroup
     slices: every slice stores its partial result to a row of its own and sf_colsum_f32 adds the
     rows (fixed order, no atomics: with 256 slices the atomic epilogues of this shape cost more
     than the products)."""
     if nsplit <= 1:
-        out = torch.empty((J, I), device=A.device, dtype=torch.float32)
+        out = torch.empty((J, I), device=A.device, dtype=out_dtype)
         ops.linear_gemm(A, B, out, I, J, R, lda, ldb, ldo, a_km, False, ops.OUT_JI, 1, bias)
         return out
     slab = torch.empty((nsplit, J * I), device=A.device, dtype=torch.float32)
     ops.linear_gemm(A, B, slab, I, J, R, lda, ldb, ldo, a_km, False, ops.OUT_JI, nsplit, bias, split_stride=J * I)
-    return ops.colsum_f32(slab).view(J, I)
+    out = ops.colsum_f32(slab).view(J, I)
+    return out if out_dtype == torch.float32 else out.to(out_dtype)
 
 
 class LinearFn(torch.autograd.Function):
@@ -172,7 +174,10 @@ class LinearFn(torch.autograd.Function):
         Nf = W.shape[0]
         if K % 8 or Nf % 8:
             raise NotImplementedError(f"Linear {K}->{Nf}: both sizes must be multiples of 8 on the HIP path")
-        xt = ops.cast(x.contiguous().float(), cdtype)
+        # an input that already has the compute dtype (the encoder's bf16 output) is taken as it is,
+        # and its gradient goes back in that dtype
+        xt = x.contiguous() if x.dtype == cdtype else ops.cast(x.contiguous().float(), cdtype)
+        ctx.x_dtype = x.dtype
         if w_shadow is not None and cdtype == torch.bfloat16 and w_shadow.shape == W.shape:
             Wt = w_shadow
         else:
@@ -194,7 +199,8 @@ class LinearFn(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             nsplit = max(1, min(256, Nf // (bk * 16)))
-            dx = _split_gemm(Wt, dyt, K, M, Nf, K, Nf, K, True, nsplit, None)
+            dx = _split_gemm(Wt, dyt, K, M, Nf, K, Nf, K, True, nsplit, None,
+                             out_dtype=ctx.x_dtype if ctx.x_dtype == torch.bfloat16 else torch.float32)
         if ctx.needs_input_grad[1]:
             dW = torch.empty((Nf, K), device=dy.device, dtype=torch.float32)
             ops.linear_gemm(dyt, xt, dW, Nf, K, M, Nf, K, K, True, True, ops.OUT_IJ, 1)

@@ -65,10 +65,8 @@ class CNNEncoder(nn.Module):
             B, T, C, H, W = x.shape
             x = x.reshape(B * T, C, H, W)
         _need_cuda(x, "CNNEncoder")
-        if self.training:
-            for m in self.encoder:
-                if isinstance(m, nn.BatchNorm2d):
-                    m.num_batches_tracked += 1
+        if self.training:      # one multi-tensor launch for all the layers' counters
+            torch._foreach_add_([m.num_batches_tracked for m in self.encoder if isinstance(m, nn.BatchNorm2d)], 1)
         return SF.EncoderFn.apply(x.float(), self.training, SF.compute_dtype(), self.target_spatial,
                                   *self._layer_params())
 
@@ -308,8 +306,8 @@ class PatchDiscriminator(nn.Module):
         for i in (2, 3, 4):
             conv, bn = m[i][0], m[i][1]
             ps += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-            if self.training:
-                bn.num_batches_tracked += 1
+        if self.training:      # one multi-tensor launch for the three counters
+            torch._foreach_add_([m[i][1].num_batches_tracked for i in (2, 3, 4)], 1)
         ps += [m[5].weight, m[5].bias]
         record = {} if (keep_record and reuse is None) else None
         out = SF.DiscriminatorFn.apply(x.float(), SF.compute_dtype(), self.training, reuse, record, *ps)

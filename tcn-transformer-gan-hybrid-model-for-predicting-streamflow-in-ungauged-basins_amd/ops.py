@@ -69,7 +69,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nchw_bf16_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
@@ -457,6 +457,7 @@ def conv_wgrad(x, dout, dw, geom: ConvGeom, K: int, nsplit: Optional[int] = None
 
 
 def linear_gemm(A, B, out, I, J, R, lda, ldb, ldo, a_km, b_km, out_mode, nsplit=1, bias=None, split_stride=0):
+    # (out may be bf16 for the JI layout without a split reduction)
     """split_stride > 0 (with nsplit > 1): `out` is a slab of nsplit partial results split_stride
     floats apart (plain stores, to be summed by the caller); 0: atomic accumulation into a zeroed out."""
     d = GemmDesc()
@@ -464,14 +465,20 @@ def linear_gemm(A, B, out, I, J, R, lda, ldb, ldo, a_km, b_km, out_mode, nsplit=
     d.dtype = code_of(A.dtype)
     d.a_kmajor, d.b_kmajor, d.b_gather = int(a_km), int(b_km), 0
     d.I, d.J, d.R, d.lda, d.ldb, d.ldo = I, J, R, lda, ldb, ldo
-    d.nsplit, d.out_mode, d.out_dtype = nsplit, out_mode, F32
+    d.nsplit, d.out_mode, d.out_dtype = nsplit, out_mode, code_of(out.dtype)
     gemm(d, A, B, out, bias)
 
 
 # ------------------------------------------------------------------------------ layout / packing
 def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cpad: int) -> torch.Tensor:
-    _dev(x, dtypes=[torch.float32])
     N, C, H, W = x.shape
+    if x.dtype == torch.bfloat16 and dtype == torch.bfloat16 and cpad >= 64:
+        _dev(x)
+        out = torch.empty((N, H, W, cpad), device=x.device, dtype=dtype)
+        _check(lib().sf_nchw_bf16_to_nhwc(_p(x), _p(out), N, C, H, W, cpad, _stream()), "sf_nchw_bf16_to_nhwc")
+        return out
+    x = x.float()
+    _dev(x, dtypes=[torch.float32])
     out = torch.empty((N, H, W, cpad), device=x.device, dtype=dtype)
     _check(lib().sf_nchw_to_nhwc(_p(x), _p(out), code_of(dtype), N, C, H, W, cpad, _stream()), "sf_nchw_to_nhwc")
     return out

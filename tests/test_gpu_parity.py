@@ -448,7 +448,7 @@ def test_bf16_backward(sf, which):
     a = _bf16_fwd_bwd(sf, which, generic=False)
     b = _bf16_fwd_bwd(sf, which, generic=True)
     for k in a:
-        close(a[k], b[k].numpy(), 2e-3)
+        close(a[k], b[k].float().numpy(), 2e-3)
     if which == "dec":
         g = golden("decoder")
         close(a["y"], g["y100"], 3e-2)
