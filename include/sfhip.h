@@ -228,6 +228,23 @@ int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* dy, int dy_d
                     const float* invstd, const float* gamma, const double* ws, int training,
                     void* dx, float* dgamma, float* dbeta, int N, int H, int W, int C, int Creal,
                     int OH, int OW, void* stream);
+/*
+ * The last encoder layer's BatchNorm -> ReLU -> AdaptiveAvgPool2d in training
+ * (src/model/cnn_encoder.py:54-56,69,88-91) with the reduction pass of its backward taken off the
+ * pre-BN map.  Both channel sums are linear in the pooled gradient g:
+ *   sum_p dz      = sum_bin g * pos / |bin|,   pos = number of pixels of the bin with x*scale+shift > 0
+ *   sum_p dz*xhat = sum_bin g * xh,            xh  = (1/|bin|) * sum over those pixels of (x-mean)*invstd
+ * sf_bn_relu_avgpool_fwd_moments is sf_bn_relu_avgpool_fwd that also writes pos (uint16) and xh
+ * (dtype), both NHWC [N,OH,OW,C]; OW <= 63, bins of at most 65535 pixels.
+ * sf_bn_bwd_reduce_pooled leaves the two sums in ws[0..2C) from dy [N,OH,OW,C] (dtype), pos and
+ * xh, exactly where sf_bn_bwd_reduce(mode 1) leaves them; sf_bn_bwd_apply(mode 1) follows.
+ */
+int sf_bn_relu_avgpool_fwd_moments(const void* x, int dtype, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, void* y, int out_dtype,
+                                   void* pos, void* xh, int N, int H, int W, int C, int Creal,
+                                   int OH, int OW, void* stream);
+int sf_bn_bwd_reduce_pooled(const void* dy, int dtype, const void* pos, const void* xh, double* ws,
+                            int N, int H, int W, int C, int OH, int OW, void* stream);
 /* out[c] = sum_m x[m][c] (bias gradients); out f32 [Creal]; ws: SF_BN_WS_DOUBLES(C) doubles. */
 int sf_channel_sum(const void* x, int dtype, long long M, int C, int Creal, float* out, double* ws,
                    void* stream);

@@ -628,6 +628,178 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply_kernel(BnBwd a, const double*
     }
 }
 
+// ------------------------------------------------------------------------------ avgpool with bin moments
+// The two channel sums of the BatchNorm backward behind ReLU + adaptive average pool are linear
+// in the pooled gradient g:  sum_p dz = sum_bin g * (positives of the bin / bin size) and
+// sum_p dz*xhat = sum_bin g * (sum of xhat over the bin's positives / bin size).  The forward pass
+// already walks every bin, so it leaves those two pooled-size factors behind (pos: count of
+// pixels with relu input > 0, u16; xh: mean over the bin of [y > 0] * xhat, compute dtype, both
+// NHWC [N,OH,OW,C]) and the backward reduction reads three pooled maps instead of the pre-BN map.
+template <int EPC> struct PosChunk;
+template <> struct PosChunk<8> {
+    using Raw = uint4;
+    static __device__ __forceinline__ Raw pack(const int* c) {
+        return make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
+    }
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
+        f[0] = (float)(r.x & 0xffffu); f[1] = (float)(r.x >> 16); f[2] = (float)(r.y & 0xffffu); f[3] = (float)(r.y >> 16);
+        f[4] = (float)(r.z & 0xffffu); f[5] = (float)(r.z >> 16); f[6] = (float)(r.w & 0xffffu); f[7] = (float)(r.w >> 16);
+    }
+};
+template <> struct PosChunk<4> {
+    using Raw = uint2;
+    static __device__ __forceinline__ Raw pack(const int* c) { return make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16)); }
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
+        f[0] = (float)(r.x & 0xffffu); f[1] = (float)(r.x >> 16); f[2] = (float)(r.y & 0xffffu); f[3] = (float)(r.y >> 16);
+    }
+};
+
+constexpr int POOL_CS = 256;   // channels per LDS slab of the NCHW transpose
+constexpr int POOL_BT = 256;   // threads of the pooling forward (its register count allows three such workgroups per CU)
+
+// One workgroup per (image, output row): a thread owns (channel chunk, output column), walks the
+// bin two rows x four columns at a time (eight unconditional loads in flight), and the pooled
+// activations go through an LDS tile so that y leaves as NCHW rows.  Per element the loop keeps
+// three sums (relu(v), [v > 0] * (x - mean), [v > 0]); invstd and 1 / |bin| are applied per bin.
+// FULL: every bin is exactly 4 x 4 (no predicates).
+template <typename T, typename TO, bool FULL>
+__global__ __launch_bounds__(POOL_BT) void bn_relu_avgpool_mom_fwd_kernel(
+    const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd, TO* __restrict__ y,
+    unsigned short* __restrict__ pos, T* __restrict__ xh, int H, int W, int C, int Creal, int OH, int OW) {
+    constexpr int EPC = Chunk<T>::EPC;
+    extern __shared__ float pool_tile[];   // [POOL_CS][OW + 1]
+    const int n = blockIdx.x / OH, oh = blockIdx.x % OH;
+    const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
+    const int ldt = OW + 1;
+    const T* img = x + (size_t)n * H * W * C;
+    for (int c0 = 0; c0 < C; c0 += POOL_CS) {
+        const int cs = (C - c0) < POOL_CS ? (C - c0) : POOL_CS;
+        const int gs = cs / EPC;
+        __syncthreads();
+        for (int it = threadIdx.x; it < gs * OW; it += POOL_BT) {
+            const int cg = it % gs, ow = it / gs;
+            const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+            const int cb = c0 + cg * EPC;
+            float sc[EPC], sf[EPC], mu[EPC], acc[EPC], accx[EPC];
+            int cnt[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                sc[e] = scale[cb + e]; sf[e] = shift[cb + e]; mu[e] = mean[cb + e];
+                acc[e] = accx[e] = 0.f; cnt[e] = 0;
+            }
+            const T* base = img + cb;
+            for (int h = h0; h < h1; h += 2)
+                for (int wq = w0; wq < w1; wq += 4) {
+                    uint4 raw[2][4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool in = FULL || (h + j < h1 && wq + k < w1);
+                            raw[j][k] = ld16(in ? (const void*)(base + ((size_t)(h + j) * W + wq + k) * C) : zsrc());
+                        }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool in = FULL || (h + j < h1 && wq + k < w1);
+                            float f[EPC];
+                            Chunk<T>::decode(raw[j][k], f);
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) {
+                                const float v = f[e] * sc[e] + sf[e];
+                                const bool p = in && !(v <= 0.f);   // one compare; true for NaN, so the ReLU keeps it
+                                acc[e] += p ? v : 0.f;
+                                accx[e] += p ? f[e] - mu[e] : 0.f;   // centred: no cancellation against the mean
+                                cnt[e] += p;
+                            }
+                        }
+                }
+            const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                pool_tile[(cg * EPC + e) * ldt + ow] = acc[e] * inv;
+                accx[e] *= invstd[cb + e] * inv;
+            }
+            const size_t row = ((size_t)n * OH + oh) * OW + ow;
+            *reinterpret_cast<typename PosChunk<EPC>::Raw*>(pos + row * C + cb) = PosChunk<EPC>::pack(cnt);
+            *reinterpret_cast<uint4*>(xh + row * C + cb) = Chunk<T>::encode(accx);
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < cs * OW; it += POOL_BT) {
+            const int ow = it % OW, c = it / OW;
+            if (c0 + c < Creal) y[(((size_t)n * Creal + c0 + c) * OH + oh) * OW + ow] = from_f32<TO>(pool_tile[c * ldt + ow]);
+        }
+    }
+}
+
+// ws slab row of this workgroup: [0,C) sum_rows g * pos / bin size, [C,2C) sum_rows g * xh
+template <typename T>
+__global__ __launch_bounds__(BT) void bn_bwd_reduce_pooled_kernel(const T* __restrict__ dy,
+                                                                  const unsigned short* __restrict__ pos,
+                                                                  const T* __restrict__ xh, unsigned M, unsigned per,
+                                                                  int C, int H, int W, int OH, int OW,
+                                                                  double* __restrict__ ws) {
+    constexpr int EPC = Chunk<T>::EPC, U = 4;
+    using PC = PosChunk<EPC>;
+    const RowMap m(C, EPC);
+    __shared__ double sm[BT];
+    __shared__ float ih[MAX_BINS], iw[MAX_BINS];
+    for (int i = threadIdx.x; i < OH; i += BT) ih[i] = 1.0f / (float)(bin_end(i, H, OH) - bin_start(i, H, OH));
+    for (int i = threadIdx.x; i < OW; i += BT) iw[i] = 1.0f / (float)(bin_end(i, W, OW) - bin_start(i, W, OW));
+    __syncthreads();
+    double s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.0;
+    const unsigned r0 = blockIdx.x * per;
+    const unsigned r1 = r0 + per < M ? r0 + per : M;
+    if (m.active) {
+        const size_t co = (size_t)m.cg * EPC;
+        for (unsigned r = r0 + m.phase; r < r1; r += m.rpp * U) {
+            uint4 rg[U], rx[U];
+            typename PC::Raw rp[U];
+            float wgt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned rr = r + u * m.rpp;
+                const bool ok = rr < r1;
+                const unsigned rc = ok ? rr : r;
+                rg[u] = ld16(ok ? (const void*)(dy + (size_t)rr * C + co) : zsrc());
+                rx[u] = ld16(ok ? (const void*)(xh + (size_t)rr * C + co) : zsrc());
+                rp[u] = *reinterpret_cast<const typename PC::Raw*>(ok ? (const void*)(pos + (size_t)rr * C + co) : zsrc());
+                const unsigned t = rc / (unsigned)OW;
+                wgt[u] = ih[t % (unsigned)OH] * iw[rc - t * OW];
+            }
+            float p1[EPC], p2[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) p1[e] = p2[e] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float g[EPC], xf[EPC], cf[EPC];
+                Chunk<T>::decode(rg[u], g);
+                Chunk<T>::decode(rx[u], xf);
+                PC::unpack(rp[u], cf);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    p1[e] += g[e] * (cf[e] * wgt[u]);
+                    p2[e] += g[e] * xf[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1[e] += (double)p1[e]; s2[e] += (double)p2[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        double* row = ws + (size_t)(1 + blockIdx.x) * (2 * C);
+        const double t1 = group_sum(s1[e], m, sm);
+        if ((int)threadIdx.x < m.G) row[threadIdx.x * EPC + e] = t1;
+        const double t2 = group_sum(s2[e], m, sm);
+        if ((int)threadIdx.x < m.G) row[C + threadIdx.x * EPC + e] = t2;
+    }
+}
+
 // rows per workgroup for `items` rows on at most `cap` workgroups, a multiple of `step`
 struct Split { unsigned per; int grid; };
 // min_batches > 1 (reductions): a workgroup gets at least that many batches, so that the
@@ -805,7 +977,60 @@ extern "C" int sf_bn_bwd_reduce(int mode, const void* x, int dtype, const void* 
     return SF_OK;
 }
 
-extern "C" int sf_bn_bwd_apply(int mode, const void* x, int dtype, const void* dy, int dy_dtype, const float* scale,
+static int pooled_shape_ok(const char* who, int dtype, int N, int H, int W, int C, int OH, int OW) {
+    SF_REQUIRE(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "%s: bad shape", who);
+    SF_REQUIRE(OH <= MAX_BINS && OW <= MAX_BINS, "%s: at most %d x %d bins", who, MAX_BINS, MAX_BINS);
+    if (int rc = check_chunked(who, dtype, C)) return rc;
+    const long long bh = (H + OH - 1) / OH + 1, bw = (W + OW - 1) / OW + 1;
+    SF_REQUIRE(bh * bw <= 65535, "%s: bins of up to %lld x %lld pixels overflow the 16-bit counts", who, bh, bw);
+    SF_REQUIRE((long long)N * OH * OW < 0x7fffffffLL, "%s: too many pooled pixels", who);
+    return SF_OK;
+}
+
+extern "C" int sf_bn_relu_avgpool_fwd_moments(const void* x, int dtype, const float* scale, const float* shift,
+                                              const float* mean, const float* invstd, void* y, int out_dtype,
+                                              void* pos, void* xh, int N, int H, int W, int C, int Creal, int OH,
+                                              int OW, void* stream) {
+    SF_REQUIRE(x && y && pos && xh && scale && shift && mean && invstd && Creal <= C,
+               "sf_bn_relu_avgpool_fwd_moments: bad arguments");
+    if (int rc = pooled_shape_ok("sf_bn_relu_avgpool_fwd_moments", dtype, N, H, W, C, OH, OW)) return rc;
+    const size_t lds = sizeof(float) * POOL_CS * (OW + 1);
+    SF_REQUIRE(lds <= 65536, "sf_bn_relu_avgpool_fwd_moments: OW=%d > 63", OW);
+    dim3 grid((unsigned)(N * OH)), block(POOL_BT);
+    hipStream_t s = (hipStream_t)stream;
+    bool full = true;   // every bin exactly 4 x 4: the walk needs no predicates
+    for (int i = 0; i < OH; ++i) full = full && ((i + 1) * H + OH - 1) / OH - (i * H) / OH == 4;
+    for (int i = 0; i < OW; ++i) full = full && ((i + 1) * W + OW - 1) / OW - (i * W) / OW == 4;
+#define POOLF(T, TO)                                                                                                    \
+    if (full) hipLaunchKernelGGL((bn_relu_avgpool_mom_fwd_kernel<T, TO, true>), grid, block, lds, s, (const T*)x, scale, \
+                                 shift, mean, invstd, (TO*)y, (unsigned short*)pos, (T*)xh, H, W, C, Creal, OH, OW);    \
+    else hipLaunchKernelGGL((bn_relu_avgpool_mom_fwd_kernel<T, TO, false>), grid, block, lds, s, (const T*)x, scale,    \
+                            shift, mean, invstd, (TO*)y, (unsigned short*)pos, (T*)xh, H, W, C, Creal, OH, OW)
+    if (dtype == SF_BF16 && out_dtype == SF_BF16) { POOLF(bf16, bf16); }
+    else if (dtype == SF_BF16 && out_dtype == SF_F32) { POOLF(bf16, float); }
+    else if (dtype == SF_F32 && out_dtype == SF_F32) { POOLF(float, float); }
+    else { sf_set_error("sf_bn_relu_avgpool_fwd_moments: unsupported dtype pair %d -> %d", dtype, out_dtype); return SF_EINVAL; }
+#undef POOLF
+    SF_LAUNCH_CHECK("sf_bn_relu_avgpool_fwd_moments");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_bwd_reduce_pooled(const void* dy, int dtype, const void* pos, const void* xh, double* ws, int N,
+                                       int H, int W, int C, int OH, int OW, void* stream) {
+    SF_REQUIRE(dy && pos && xh && ws, "sf_bn_bwd_reduce_pooled: null argument");
+    if (int rc = pooled_shape_ok("sf_bn_bwd_reduce_pooled", dtype, N, H, W, C, OH, OW)) return rc;
+    const int epc = dtype == SF_BF16 ? 8 : 4;
+    const long long M = (long long)N * OH * OW;
+    const Split sp = split_rows(M, (BT / (C / epc)) * 4, SF_BN_WS_PARTS, 4);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_pooled_kernel<T>), dim3(sp.grid), dim3(BT), 0, s, (const T*)dy,
+                                         (const unsigned short*)pos, (const T*)xh, (unsigned)M, sp.per, C, H, W, OH, OW, ws));
+    hipLaunchKernelGGL(ws_fold_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, 2 * C, sp.grid);
+    SF_LAUNCH_CHECK("sf_bn_bwd_reduce_pooled");
+    return SF_OK;
+}
+
+extern "C" int sf_bn_bwd_apply(int mode,const void* x, int dtype, const void* dy, int dy_dtype, const float* scale,
                                const float* shift, const float* mean, const float* invstd, const float* gamma,
                                const double* ws, int training, void* dx, float* dgamma, float* dbeta, int N, int H,
                                int W, int C, int Creal, int OH, int OW, void* stream) {

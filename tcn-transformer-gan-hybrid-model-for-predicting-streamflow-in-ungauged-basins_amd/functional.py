@@ -95,14 +95,21 @@ class EncoderFn(torch.autograd.Function):
                 ws = ops.bn_ws(Kpad, x.device)
                 ops.bn_stats(z, M, Kpad, ws)
             st = ops.bn_finalize(ws, M, Kpad, K, gamma.detach(), beta.detach(), rm, rv, training)
-            saved.append((a, z, st, (h, w), None))
             if l < L - 1:
+                saved.append((a, z, st, (h, w), None))
                 a = ops.bn_relu_maxpool_fwd(z, st)
                 h, w = h // 2, w // 2
             else:
                 oh, ow = (target, target) if (h != target or w != target) else (h, w)
                 # bf16 mode: the feature map leaves in bf16 (what the Linear layer behind it rounds to anyway)
-                out = ops.bn_relu_avgpool_fwd(z, st, K, oh, ow, cdtype if cdtype == torch.bfloat16 else torch.float32)
+                odt = cdtype if cdtype == torch.bfloat16 else torch.float32
+                if training and ops.avgpool_moments_ok(h, w, oh, ow):
+                    # the pooling pass also leaves what the backward's channel sums need (one read of z less)
+                    out, pos, xh = ops.bn_relu_avgpool_fwd_moments(z, st, K, oh, ow, odt)
+                    saved.append((a, z, st, (h, w), (pos, xh)))
+                else:
+                    out = ops.bn_relu_avgpool_fwd(z, st, K, oh, ow, odt)
+                    saved.append((a, z, st, (h, w), None))
         ctx.saved = saved
         ctx.params = params
         ctx.training = training
@@ -130,7 +137,8 @@ class EncoderFn(torch.autograd.Function):
                 continue
             K, Kpad, C = wt.shape[0], z.shape[-1], a.shape[-1]
             mode = 1 if l == L - 1 else 0
-            dz, dgamma, dbeta = ops.bn_backward(mode, z, dy, st, gamma.detach(), K, training, oh, ow)
+            dz, dgamma, dbeta = ops.bn_backward(mode, z, dy, st, gamma.detach(), K, training, oh, ow,
+                                                moments=wp if mode == 1 else None)
             dw = torch.empty_like(wt)
             ops.wgrad3x3(a, dz, dw)
             grads[5 * l], grads[5 * l + 1], grads[5 * l + 2] = dw, dgamma, dbeta

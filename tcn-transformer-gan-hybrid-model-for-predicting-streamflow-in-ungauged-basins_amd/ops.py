@@ -71,7 +71,7 @@ def lib():
 
 EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nchw_bf16_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
-           "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_channel_sum", "sf_colsum_f32",
+           "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_bn_relu_avgpool_fwd_moments", "sf_bn_bwd_reduce_pooled", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
            "sf_conv_k1_fwd", "sf_conv_k1_fwd_ws", "sf_conv_k1_fwd_workspace_bytes", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
@@ -605,6 +605,25 @@ def bn_relu_avgpool_fwd(x, st, Creal, OH, OW, out_dtype):
     return y
 
 
+def avgpool_moments_ok(H: int, W: int, OH: int, OW: int) -> bool:
+    """Shapes sf_bn_relu_avgpool_fwd_moments takes (LDS tile of the NCHW transpose, 16-bit counts)."""
+    return OW <= 63 and OH <= 256 and (-(-H // OH) + 1) * (-(-W // OW) + 1) <= 65535
+
+
+def bn_relu_avgpool_fwd_moments(x, st, Creal, OH, OW, out_dtype):
+    """(y NCHW, pos u16 NHWC, xh NHWC): the pooled activation and, per bin, the count of positive
+    pixels and the bin mean of [y > 0] * xhat, from which bn_backward forms its channel sums."""
+    _dev(x, st)
+    N, H, W, C = x.shape
+    y = torch.empty((N, Creal, OH, OW), device=x.device, dtype=out_dtype)
+    pos = torch.empty((N, OH, OW, C), device=x.device, dtype=torch.uint16)
+    xh = torch.empty((N, OH, OW, C), device=x.device, dtype=x.dtype)
+    _check(lib().sf_bn_relu_avgpool_fwd_moments(_p(x), code_of(x.dtype), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
+                                                _p(y), code_of(out_dtype), _p(pos), _p(xh), N, H, W, C, Creal, OH, OW,
+                                                _stream()), "sf_bn_relu_avgpool_fwd_moments")
+    return y, pos, xh
+
+
 def enc1_ok(x: torch.Tensor, K: int) -> bool:
     """The fused first-layer kernels take bf16 NHWC input with 16 (padded) channels."""
     N, H, W, _ = x.shape
@@ -672,14 +691,25 @@ def relu_dropout_bwd(y: torch.Tensor, dy: torch.Tensor, p: float) -> torch.Tenso
     return dx
 
 
-def bn_backward(mode, x, dy, st, gamma, Creal, training, OH=0, OW=0):
-    """Returns (dx, dgamma, dbeta); see sf_bn_bwd_reduce / sf_bn_bwd_apply."""
+def bn_backward(mode, x, dy, st, gamma, Creal, training, OH=0, OW=0, moments=None):
+    """Returns (dx, dgamma, dbeta); see sf_bn_bwd_reduce / sf_bn_bwd_apply.  moments = (pos, xh) of
+    bn_relu_avgpool_fwd_moments (mode 1): the channel sums come from the pooled maps instead of x."""
     _dev(x, dy, st, gamma)
     N, H, W, C = x.shape
     ws = bn_ws(C, x.device)
     c = code_of(x.dtype)
-    _check(lib().sf_bn_bwd_reduce(mode, _p(x), c, _p(dy), code_of(dy.dtype), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
-                                  _p(ws), N, H, W, C, Creal, OH, OW, _stream()), "sf_bn_bwd_reduce")
+    if moments is not None:
+        if mode != 1 or dy.dtype != x.dtype:
+            raise RuntimeError("bn_backward: bin moments belong to the avgpool mode, in x's dtype")
+        pos, xh = moments
+        _dev(pos, xh, dtypes=[torch.uint16, x.dtype])
+        if tuple(pos.shape) != (N, OH, OW, C) or tuple(xh.shape) != (N, OH, OW, C) or tuple(dy.shape) != (N, OH, OW, C):
+            raise RuntimeError("bn_backward: bin moments / pooled gradient must be [N, OH, OW, C]")
+        _check(lib().sf_bn_bwd_reduce_pooled(_p(dy), c, _p(pos), _p(xh), _p(ws), N, H, W, C, OH, OW, _stream()),
+               "sf_bn_bwd_reduce_pooled")
+    else:
+        _check(lib().sf_bn_bwd_reduce(mode, _p(x), c, _p(dy), code_of(dy.dtype), _p(st[0]), _p(st[1]), _p(st[2]),
+                                      _p(st[3]), _p(ws), N, H, W, C, Creal, OH, OW, _stream()), "sf_bn_bwd_reduce")
     dx = torch.empty_like(x)
     dgamma = torch.empty(Creal, device=x.device, dtype=torch.float32)
     dbeta = torch.empty(Creal, device=x.device, dtype=torch.float32)

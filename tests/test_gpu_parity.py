@@ -752,6 +752,68 @@ def test_bn_avgpool_backward_shapes(sf):
         close(dbeta, br.grad.numpy(), 1e-4)
 
 
+def test_bn_avgpool_bin_moments(sf):
+    """sf_bn_relu_avgpool_fwd_moments + sf_bn_bwd_reduce_pooled (the training path of the last encoder
+    layer's BatchNorm -> ReLU -> adaptive_avg_pool2d, src/model/cnn_encoder.py:54-56,69,88-91): the
+    pooled map equals sf_bn_relu_avgpool_fwd's (1e-6), the positive counts are exact, and the
+    backward through the bin moments matches torch autograd (f32: 1e-4) and the reduction over the
+    pre-BN map (bf16: both see the same rounded inputs, 5e-3 of the largest sum).  Shapes: overlapping
+    4-wide bins, ragged bins, exact 2 x 2 bins, no pooling (bins of one pixel), padded channels."""
+    ops = sf.ops
+    torch.manual_seed(12)
+    for (N, H, W, C, Creal, OH, OW) in [(3, 100, 100, 256, 256, 32, 32), (2, 90, 110, 16, 16, 32, 32),
+                                        (2, 45, 67, 8, 5, 32, 32), (2, 64, 64, 8, 8, 32, 32),
+                                        (2, 32, 32, 16, 12, 32, 32), (1, 33, 131, 264, 264, 32, 32)]:
+        for dt in (torch.float32, torch.bfloat16):
+            if dt == torch.bfloat16 and C % 8:
+                continue
+            x = torch.randn(N, H, W, C, device=DEV)
+            x[..., Creal:] = 0
+            x = x.to(dt)
+            gamma, beta = torch.rand(Creal, device=DEV) + 0.5, torch.randn(Creal, device=DEV) * 0.3
+            dy = torch.randn(N, OH, OW, C, device=DEV)
+            dy[..., Creal:] = 0
+            dy = dy.to(dt)
+            M = N * H * W
+            ws = ops.bn_ws(C, DEV)
+            ops.bn_stats(x, M, C, ws)
+            st = ops.bn_finalize(ws[:2 * C], M, C, Creal, gamma, beta, torch.zeros(Creal, device=DEV),
+                                 torch.ones(Creal, device=DEV), True)
+            assert ops.avgpool_moments_ok(H, W, OH, OW)
+            y0 = ops.bn_relu_avgpool_fwd(x, st, Creal, OH, OW, torch.float32)
+            y, pos, xh = ops.bn_relu_avgpool_fwd_moments(x, st, Creal, OH, OW, torch.float32)
+            close(y, y0.cpu().numpy(), 1e-6)
+            # counts of positive pixels per bin against a torch restatement on the same f32 expression
+            yb = (x.float() * st[0] + st[1]).permute(0, 3, 1, 2)
+            cnt_bin = torch.zeros(OH, OW, device=DEV)
+            for i in range(OH):
+                for j in range(OW):
+                    h0, h1 = (i * H) // OH, -((-(i + 1) * H) // OH)
+                    w0, w1 = (j * W) // OW, -((-(j + 1) * W) // OW)
+                    cnt_bin[i, j] = (h1 - h0) * (w1 - w0)
+            want_pos = torch.nn.functional.adaptive_avg_pool2d((yb > 0).float(), (OH, OW)) * cnt_bin
+            got_pos = pos.view(torch.int16).to(torch.int32).permute(0, 3, 1, 2).float()
+            assert torch.equal(got_pos[:, :Creal], torch.round(want_pos[:, :Creal])), (H, W, C, dt)
+            dx, dgamma, dbeta = ops.bn_backward(1, x, dy, st, gamma, Creal, True, OH, OW, moments=(pos, xh))
+            dx0, dgamma0, dbeta0 = ops.bn_backward(1, x, dy, st, gamma, Creal, True, OH, OW)
+            if dt == torch.float32:
+                xr = x[..., :Creal].cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+                gr, br = gamma.cpu().requires_grad_(True), beta.cpu().requires_grad_(True)
+                yy = torch.nn.functional.adaptive_avg_pool2d(
+                    torch.relu(torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)), (OH, OW))
+                (yy * dy[..., :Creal].cpu().permute(0, 3, 1, 2)).sum().backward()
+                close(dx[..., :Creal].permute(0, 3, 1, 2), xr.grad.numpy(), 1e-4)
+                close(dgamma, gr.grad.numpy(), 1e-4)
+                close(dbeta, br.grad.numpy(), 1e-4)
+                assert bool(torch.isfinite(dx).all())
+            else:
+                scale = float(torch.maximum(dgamma0.abs().max(), dbeta0.abs().max()))
+                assert float((dgamma - dgamma0).abs().max()) <= 5e-3 * scale
+                assert float((dbeta - dbeta0).abs().max()) <= 5e-3 * scale
+                close(dx.float(), dx0.float().cpu().numpy(), 1e-2)
+                assert bool(torch.isfinite(dx.float()).all())
+
+
 def test_colsum_f32_shapes(sf):
     """Bias-gradient column sums of the two Linear layers (short and very wide, tall and narrow),
     odd sizes and a single element, against a float64 sum."""
