@@ -155,6 +155,99 @@ class EncoderFn(torch.autograd.Function):
         return (dx, None, None, None, *grads)
 
 
+class EncoderGeneralFn(torch.autograd.Function):
+    """CNNEncoder.forward for the constructor options the model class itself never uses
+    (src/model/cnn_encoder.py:16-18,44-61): kernel_size k with k * k <= 16 taps, any padding, and
+    use_batchnorm=False (convs with bias, no normalisation).  Every conv runs on the gathered GEMM
+    (forward, data gradient, weight gradient); a layer without BatchNorm goes through the
+    BatchNorm passes with scale 1, shift = bias and frozen statistics, whose shift gradient is the
+    bias gradient.  layers: per layer the number of parameters it owns (5: w, gamma, beta,
+    running_mean, running_var; 2: w, bias)."""
+
+    @staticmethod
+    def forward(ctx, x, training, cdtype, target, ksize, pad, layers, *params):
+        N, Cin, H, W = x.shape
+        a = ops.nchw_to_nhwc(x.contiguous(), cdtype, ops.roundup(Cin, 8))
+        taps = [(r - pad, s - pad) for r in range(ksize) for s in range(ksize)]
+        saved, h, w, pi, out = [], H, W, 0, None
+        L = len(layers)
+        for l, np_ in enumerate(layers):
+            ps = params[pi: pi + np_]
+            pi += np_
+            wt = ps[0]
+            K, Kpad, C = wt.shape[0], ops.roundup(wt.shape[0], 8), a.shape[-1]
+            oh, ow = h + 2 * pad - ksize + 1, w + 2 * pad - ksize + 1
+            if oh < 1 or ow < 1:
+                raise ValueError("CNNEncoder: the feature map vanished (kernel_size / padding against the image size)")
+            wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(ksize * ksize)), False, Kpad, C)
+            z = torch.empty((N, oh, ow, Kpad), device=x.device, dtype=cdtype)
+            ops.conv_fprop(a, wp, z, ops.conv_geom(N, h, w, C, oh, ow, 1, 1, oh, ow, taps), Kpad)
+            M = N * oh * ow
+            if np_ == 5:
+                ws = None
+                if training:
+                    ws = ops.bn_ws(Kpad, x.device)
+                    ops.bn_stats(z, M, Kpad, ws)
+                st = ops.bn_finalize(ws, M, Kpad, K, ps[1].detach(), ps[2].detach(), ps[3], ps[4], training)
+            else:
+                st = torch.zeros((4, Kpad), device=x.device, dtype=torch.float32)
+                st[0, :K] = 1.0
+                st[1, :K] = ps[1].detach()
+                st[3, :K] = 1.0
+            saved.append((a, z, st, (h, w)))
+            if l < L - 1:
+                a = ops.bn_relu_maxpool_fwd(z, st)
+                h, w = oh // 2, ow // 2
+            else:
+                th, tw = (target, target) if (oh != target or ow != target) else (oh, ow)
+                out = ops.bn_relu_avgpool_fwd(z, st, K, th, tw, torch.float32)
+        ctx.saved, ctx.params, ctx.layers = saved, params, layers
+        ctx.training, ctx.cdtype, ctx.geom = training, cdtype, (ksize, pad, Cin)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params, layers, cdtype = ctx.params, ctx.layers, ctx.cdtype
+        ksize, pad, Cin = ctx.geom
+        taps = [(r - pad, s - pad) for r in range(ksize) for s in range(ksize)]
+        taps_T = [(pad - r, pad - s) for r in range(ksize) for s in range(ksize)]
+        rs = list(range(ksize * ksize))
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        L = len(layers)
+        K_last = params[sum(layers[:-1])].shape[0]
+        dy = ops.nchw_to_nhwc(dout.contiguous().float(), cdtype, ops.roundup(K_last, 8))
+        th, tw = dout.shape[-2], dout.shape[-1]
+        dx = None
+        for l in range(L - 1, -1, -1):
+            pi = sum(layers[:l])
+            ps = params[pi: pi + layers[l]]
+            wt = ps[0]
+            a, z, st, (h, w) = ctx.saved[l]
+            N, oh, ow, Kpad = z.shape
+            K, C = wt.shape[0], a.shape[-1]
+            bn = layers[l] == 5
+            gamma = ps[1].detach() if bn else torch.ones(K, device=z.device)
+            dz, dgamma, dbeta = ops.bn_backward(1 if l == L - 1 else 0, z, dy, st, gamma, K, ctx.training and bn, th, tw)
+            dw = torch.zeros_like(wt)
+            ops.conv_wgrad(a, dz, dw, ops.conv_geom(N, h, w, C, oh, ow, 1, 1, oh, ow, taps, tap_rs=rs,
+                                                    cin_real=wt.shape[1], RS=ksize * ksize), Kpad)
+            grads[pi] = dw
+            if bn:
+                grads[pi + 1], grads[pi + 2] = dgamma, dbeta
+            else:
+                grads[pi + 1] = dbeta
+            if l > 0 or ctx.needs_input_grad[0]:
+                wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, rs, True, C, Kpad)
+                da = torch.empty((N, h, w, C), device=dz.device, dtype=cdtype)
+                ops.conv_fprop(dz, wT, da, ops.conv_geom(N, oh, ow, Kpad, h, w, 1, 1, h, w, taps_T), C)
+                if l > 0:
+                    dy = da
+                else:
+                    dx = ops.nhwc_to_nchw(da, Cin)
+        ctx.saved = None
+        return (dx, None, None, None, None, None, None, *grads)
+
+
 # ------------------------------------------------------------------------------ 262144-wide Linear
 def _split_gemm(A, B, I, J, R, lda, ldb, ldo, a_km, nsplit, bias, out_dtype=torch.float32):
     """out f32 [J][I] = B[J][R] . A^T (+ bias) with the reduction split over nsplit workgroup
@@ -445,6 +538,7 @@ class DiscriminatorFn(torch.autograd.Function):
                 ops.bn_finalize(reuse["wss"][i], z.shape[0] * z.shape[1] * z.shape[2], K, K, gamma.detach(), beta.detach(),
                                 rm, rv, True)
             ctx.x, ctx.acts, ctx.zs, ctx.sts = reuse["x"], reuse["acts"], reuse["zs"], reuse["sts"]
+            ctx.xin = reuse.get("xin")
             ctx.params = (w1, b1, *rest)
             ctx.cdtype = cdtype
             ctx.training = True
@@ -455,7 +549,20 @@ class DiscriminatorFn(torch.autograd.Function):
         K1 = w1.shape[0]
         if K1 % 8:
             raise NotImplementedError("discriminator width must be a multiple of 8 on the HIP path")
-        y = ops.dconv1_fwd(x, w1c, b1c, cdtype)
+        Cin = w1.shape[1]
+        xin = None
+        if Cin == 1:
+            y = ops.dconv1_fwd(x, w1c, b1c, cdtype)
+        else:
+            # several input channels (src/model/gan.py:10,25): the first layer as a gathered GEMM
+            Cp = ops.roundup(Cin, 8)
+            xin = ops.nchw_to_nhwc(x, cdtype, Cp)
+            oh1, ow1 = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+            if oh1 < 1 or ow1 < 1:
+                raise ValueError("input too small for the PatchGAN discriminator")
+            y = torch.empty((N, oh1, ow1, K1), device=x.device, dtype=cdtype)
+            ops.conv_fprop(xin, ops.pack_conv_weight(w1c, cdtype, list(range(16)), False, K1, Cp), y,
+                           _s2_geom(N, H, W, Cp, oh1, ow1), K1, bias=b1c, act=ops.ACT_LRELU)
         acts = [y]
         zs, sts, wss = [], [], []
         for i in range(3):
@@ -485,12 +592,12 @@ class DiscriminatorFn(torch.autograd.Function):
         w5, b5 = rest[18], rest[19]
         w5c = w5.detach().contiguous()
         out = ops.conv_k1_fwd(y, w5c, b5.detach().contiguous(), 4, 1)
-        ctx.x, ctx.acts, ctx.zs, ctx.sts = x, acts, zs, sts
+        ctx.x, ctx.acts, ctx.zs, ctx.sts, ctx.xin = x, acts, zs, sts, xin
         ctx.params = (w1, b1, *rest)
         ctx.cdtype = cdtype
         ctx.training = training
         if record is not None:      # the caller asked for the activations (to pass them back as `reuse`)
-            record.update({"x": x, "acts": acts, "zs": zs, "sts": sts, "wss": wss, "out": out})
+            record.update({"x": x, "acts": acts, "zs": zs, "sts": sts, "wss": wss, "out": out, "xin": xin})
         return out
 
     @staticmethod
@@ -537,13 +644,30 @@ class DiscriminatorFn(torch.autograd.Function):
                 problems.append((dz, wT, dyin, geom, C, yin if i == 0 else None, 2 if i == 0 else 0))
             ops.conv_fprop_batch(problems)   # the four parity classes in one launch
             dy = dyin
-        if need_w:
-            dw1, db1 = ops.dconv1_bwd_weight(x, dy)
-            grads[0], grads[1] = dw1, db1
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.dconv1_bwd_data(dy, w1.detach().contiguous(), x.shape[2], x.shape[3])
-        ctx.x = ctx.acts = ctx.zs = ctx.sts = None
+        if ctx.xin is None:
+            if need_w:
+                dw1, db1 = ops.dconv1_bwd_weight(x, dy)
+                grads[0], grads[1] = dw1, db1
+            if ctx.needs_input_grad[0]:
+                dx = ops.dconv1_bwd_data(dy, w1.detach().contiguous(), x.shape[2], x.shape[3])
+        else:
+            xin, (K1, Cin) = ctx.xin, w1.shape[:2]
+            H, W, Cp, oh1, ow1 = xin.shape[1], xin.shape[2], xin.shape[3], dy.shape[1], dy.shape[2]
+            if need_w:
+                dw1 = torch.zeros_like(w1)
+                ops.conv_wgrad(xin, dy, dw1, _s2_wgeom(N, H, W, Cp, oh1, ow1, Cin), K1)
+                grads[0], grads[1] = dw1, ops.channel_sum(dy, K1)
+            if ctx.needs_input_grad[0]:
+                dxin = torch.zeros_like(xin)
+                problems = []
+                for (py, px, taps, rs, mh, mw) in _s2_dgrad_classes(H, W):
+                    wT = ops.pack_conv_weight(w1.detach().contiguous(), cdtype, rs, True, Cp, K1)
+                    geom = ops.conv_geom(N, oh1, ow1, K1, mh, mw, 1, 1, H, W, taps, osh=2, osw=2, ooy=py, oox=px)
+                    problems.append((dy, wT, dxin, geom, Cp, None, 0))
+                ops.conv_fprop_batch(problems)
+                dx = ops.nhwc_to_nchw(dxin, Cin)
+        ctx.x = ctx.acts = ctx.zs = ctx.sts = ctx.xin = None
         return (dx, None, None, None, None, *grads)
 
 

@@ -30,19 +30,20 @@ class CNNEncoder(nn.Module):
     def __init__(self, input_channels: int, hidden_dim: int, num_layers: int = 2, kernel_size: int = 3,
                  padding: int = 1, use_batchnorm: bool = True):
         super().__init__()
-        if kernel_size != 3 or padding != 1 or not use_batchnorm:
-            raise NotImplementedError("the HIP encoder implements the reference's configuration only: "
-                                      "3x3 convolutions, padding 1, BatchNorm")
+        if kernel_size < 1 or kernel_size * kernel_size > 16 or padding < 0:
+            raise NotImplementedError("the HIP encoder gathers at most 16 filter taps: kernel_size 1 to 4")
         self.input_channels = input_channels
         self.hidden_dim = hidden_dim
         self.num_layers = num_layers
+        self.kernel_size, self.padding, self.use_batchnorm = kernel_size, padding, use_batchnorm
         self.target_spatial = 32
         layers: List[nn.Module] = []
         in_ch = input_channels
         for i in range(num_layers):
             out_ch = hidden_dim * (2 ** i)
-            layers.append(nn.Conv2d(in_ch, out_ch, kernel_size=3, padding=1, bias=False))
-            layers.append(nn.BatchNorm2d(out_ch))
+            layers.append(nn.Conv2d(in_ch, out_ch, kernel_size=kernel_size, padding=padding, bias=not use_batchnorm))
+            if use_batchnorm:
+                layers.append(nn.BatchNorm2d(out_ch))
             layers.append(nn.ReLU(inplace=True))
             if i < num_layers - 1:
                 layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
@@ -56,8 +57,11 @@ class CNNEncoder(nn.Module):
         mods = list(self.encoder)
         for i, m in enumerate(mods):
             if isinstance(m, nn.Conv2d):
-                bn = mods[i + 1]
-                ps += [m.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+                if self.use_batchnorm:
+                    bn = mods[i + 1]
+                    ps += [m.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+                else:
+                    ps += [m.weight, m.bias]
         return ps
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -65,8 +69,14 @@ class CNNEncoder(nn.Module):
             B, T, C, H, W = x.shape
             x = x.reshape(B * T, C, H, W)
         _need_cuda(x, "CNNEncoder")
-        if self.training:      # one multi-tensor launch for all the layers' counters
+        if self.training and self.use_batchnorm:      # one multi-tensor launch for all the layers' counters
             torch._foreach_add_([m.num_batches_tracked for m in self.encoder if isinstance(m, nn.BatchNorm2d)], 1)
+        if (self.kernel_size, self.padding, self.use_batchnorm) != (3, 1, True):
+            # options the model class never passes: gathered-GEMM convs, no specialised kernels
+            return SF.EncoderGeneralFn.apply(x.float(), self.training, SF.compute_dtype(), self.target_spatial,
+                                             self.kernel_size, self.padding,
+                                             tuple([5 if self.use_batchnorm else 2] * self.num_layers),
+                                             *self._layer_params())
         return SF.EncoderFn.apply(x.float(), self.training, SF.compute_dtype(), self.target_spatial,
                                   *self._layer_params())
 
@@ -276,9 +286,6 @@ class PatchDiscriminator(nn.Module):
 
     def __init__(self, input_channels: int = 1, hidden_channels: int = 64):
         super().__init__()
-        if input_channels != 1:
-            raise NotImplementedError("the HIP discriminator takes the single-channel flow map of the reference")
-
         def conv_block(i, o):
             return nn.Sequential(nn.Conv2d(i, o, kernel_size=4, stride=2, padding=1), nn.BatchNorm2d(o),
                                  nn.LeakyReLU(0.2, inplace=True))

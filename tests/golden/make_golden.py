@@ -179,6 +179,54 @@ def gen_disc():
     save("discriminator", **out)
 
 
+# ------------------------------------------------------------------ 5b. constructor options
+OPTION_CASES = (("nobn", dict(kernel_size=3, padding=1, use_batchnorm=False), 72),
+                ("k4p2", dict(kernel_size=4, padding=2, use_batchnorm=True), 70),
+                ("k1p0nobn", dict(kernel_size=1, padding=0, use_batchnorm=False), 64),
+                ("k2p0", dict(kernel_size=2, padding=0, use_batchnorm=True), 90))
+
+
+def gen_options():
+    """Options the model class never passes but the constructors accept: CNNEncoder(kernel_size,
+    padding, use_batchnorm) and PatchDiscriminator(input_channels != 1).  Train-mode forward, every
+    parameter gradient, the input gradient and the BatchNorm buffers."""
+    out = {}
+    for tag, kw, size in OPTION_CASES:
+        enc = CNNEncoder(input_channels=3, hidden_dim=8, num_layers=2, **kw)
+        load_gold(enc, "encopt_" + tag)
+        enc.train()
+        x = G.gold_tensor(f"encopt/x_{tag}", (2, 3, size, size)).requires_grad_(True)
+        y = enc(x)
+        gy = G.gold_tensor(f"encopt/gy_{tag}", tuple(y.shape))
+        (y * gy).sum().backward()
+        out[f"enc_{tag}_y"] = y
+        out[f"enc_{tag}_gx"] = x.grad
+        for n, p in enc.named_parameters():
+            out[f"enc_{tag}_g_{n}"] = p.grad
+        for k, v in enc.state_dict().items():
+            if "running" in k:
+                out[f"enc_{tag}_buf_{k}"] = v.clone()
+        load_gold(enc, "encopt_" + tag)
+        enc.eval()
+        with torch.no_grad():
+            out[f"enc_{tag}_y_eval"] = enc(x.detach())
+    d = PatchDiscriminator(3, 16)
+    load_gold(d, "disc3")
+    d.train()
+    x = G.gold_tensor("disc3/x", (2, 3, 50, 50)).requires_grad_(True)
+    y = d(x)
+    gy = G.gold_tensor("disc3/gy", tuple(y.shape))
+    (y * gy).sum().backward()
+    out["disc3_y"] = y
+    out["disc3_gx"] = x.grad
+    for k, v in d.state_dict().items():
+        if "running" in k:
+            out[f"disc3_buf_{k}"] = v.clone()
+    for n, p in d.named_parameters():
+        out[f"disc3_g_{n}"] = p.grad
+    save("options", **out)
+
+
 # ------------------------------------------------------------------ 6. losses
 def station_cases(H, W):
     pos = [
@@ -571,10 +619,10 @@ def gen_baselines():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pixel", "encoder", "temporal", "decoder", "disc", "losses", "generator",
-                             "train", "evaluate", "dataset", "ckpt", "baselines", "evaluate_csv", "disc_eval"]
+                             "train", "evaluate", "dataset", "ckpt", "baselines", "evaluate_csv", "disc_eval", "options"]
     fns = {"pixel": gen_pixel, "encoder": gen_encoder, "temporal": gen_temporal, "decoder": gen_decoder,
            "disc": gen_disc, "losses": gen_losses, "generator": gen_generator, "train": gen_train,
            "evaluate": gen_evaluate, "dataset": gen_dataset, "ckpt": gen_ckpt, "baselines": gen_baselines,
-           "evaluate_csv": gen_evaluate_csv, "disc_eval": gen_disc_eval}
+           "evaluate_csv": gen_evaluate_csv, "disc_eval": gen_disc_eval, "options": gen_options}
     for w in which:
         fns[w]()

@@ -814,6 +814,66 @@ def test_bn_avgpool_bin_moments(sf):
                 assert bool(torch.isfinite(dx.float()).all())
 
 
+@pytest.mark.parametrize("tag,k,pad,bn,size", [("nobn", 3, 1, False, 72), ("k4p2", 4, 2, True, 70),
+                                               ("k1p0nobn", 1, 0, False, 64), ("k2p0", 2, 0, True, 90)])
+def test_encoder_constructor_options_f32(sf, tag, k, pad, bn, size):
+    """CNNEncoder(kernel_size, padding, use_batchnorm) (src/model/cnn_encoder.py:16-18,44-61) against
+    the reference's own outputs: eval and train forward 1e-5, BatchNorm buffers 1e-5, parameter and
+    input gradients 1e-4 (robust to ReLU / pooling decisions at rounding distance)."""
+    g = golden("options")
+    enc = sf.CNNEncoder(3, 8, 2, kernel_size=k, padding=pad, use_batchnorm=bn).to(DEV)
+    load_gold(enc, "encopt_" + tag)
+    x0 = G.gold_tensor(f"encopt/x_{tag}", (2, 3, size, size)).to(DEV)
+    enc.eval()
+    with torch.no_grad():
+        close(enc(x0), g[f"enc_{tag}_y_eval"], 1e-5)
+    enc.train()
+    x = x0.clone().requires_grad_(True)
+    y = enc(x)
+    close(y, g[f"enc_{tag}_y"], 1e-5)
+    close_elementwise(y, g[f"enc_{tag}_y"])
+    (y * G.gold_tensor(f"encopt/gy_{tag}", tuple(y.shape)).to(DEV)).sum().backward()
+    close_robust(x.grad, g[f"enc_{tag}_gx"], 1e-4)
+    for n, p in enc.named_parameters():
+        close(p.grad, g[f"enc_{tag}_g_{n}"], 1e-4)
+    for key, v in enc.state_dict().items():
+        if "running" in key:
+            close(v, g[f"enc_{tag}_buf_{key}"], 1e-5)
+    sf.set_compute_dtype(torch.bfloat16)     # the same options in bf16 mode: stated 3e-2 of the max
+    try:
+        load_gold(enc, "encopt_" + tag)
+        close(enc(x0), g[f"enc_{tag}_y"], 3e-2)
+    finally:
+        sf.set_compute_dtype(None)
+
+
+def test_discriminator_three_input_channels_f32(sf):
+    """PatchDiscriminator(input_channels=3) (src/model/gan.py:10,25) against the reference."""
+    g = golden("options")
+    d = sf.PatchDiscriminator(3, 16).to(DEV)
+    load_gold(d, "disc3")
+    d.train()
+    x = G.gold_tensor("disc3/x", (2, 3, 50, 50)).to(DEV).requires_grad_(True)
+    y = d(x)
+    close(y, g["disc3_y"], 1e-5)
+    (y * G.gold_tensor("disc3/gy", tuple(y.shape)).to(DEV)).sum().backward()
+    close_robust(x.grad, g["disc3_gx"], 1e-4)
+    for key, v in d.state_dict().items():
+        if "running" in key:
+            close(v, g[f"disc3_buf_{key}"], 1e-5)
+    for n, p in d.named_parameters():
+        if n in ("model.2.0.bias", "model.3.0.bias", "model.4.0.bias"):
+            assert float(p.grad.abs().max()) < 1e-4      # zero in front of a train-mode BatchNorm
+        else:
+            close(p.grad, g[f"disc3_g_{n}"], 1e-3)
+    sf.set_compute_dtype(torch.bfloat16)
+    try:
+        load_gold(d, "disc3")
+        close(d(x.detach()), g["disc3_y"], 5e-2)
+    finally:
+        sf.set_compute_dtype(None)
+
+
 def test_colsum_f32_shapes(sf):
     """Bias-gradient column sums of the two Linear layers (short and very wide, tall and narrow),
     odd sizes and a single element, against a float64 sum."""

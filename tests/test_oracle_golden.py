@@ -456,3 +456,66 @@ def test_discriminator_eval_mode(size):
     close_robust(x.grad, g[f"gx{size}"], 1e-4)
     close(sd["model.3.1.weight"].grad, g[f"g{size}_bn_w"], 1e-3)
     close(sd["model.3.0.weight"].grad, g[f"g{size}_conv_w"], 1e-3)
+
+
+# ------------------------------------------------------------------ constructor options
+OPTION_CASES = (("nobn", 3, 1, False, 72), ("k4p2", 4, 2, True, 70), ("k1p0nobn", 1, 0, False, 64), ("k2p0", 2, 0, True, 90))
+
+
+def encoder_option_shapes(cin, hd, k, bn):
+    s, ch, idx = {}, [cin, hd, hd * 2], 0
+    for li in range(2):
+        s[f"encoder.{idx}.weight"] = (ch[li + 1], ch[li], k, k)
+        if bn:
+            for nm in ("weight", "bias", "running_mean", "running_var"):
+                s[f"encoder.{idx + 1}.{nm}"] = (ch[li + 1],)
+            s[f"encoder.{idx + 1}.num_batches_tracked"] = ()
+        else:
+            s[f"encoder.{idx}.bias"] = (ch[li + 1],)
+        idx += (3 if bn else 2) + 1
+    return s
+
+
+@pytest.mark.parametrize("tag,k,pad,bn,size", OPTION_CASES)
+def test_encoder_constructor_options(tag, k, pad, bn, size):
+    """CNNEncoder(kernel_size, padding, use_batchnorm) (src/model/cnn_encoder.py:16-18,44-61): the
+    oracle against the reference's outputs, gradients and BatchNorm buffers."""
+    g = golden("options")
+    sd = gstate(encoder_option_shapes(3, 8, k, bn), "encopt_" + tag)
+    x0 = G.gold_tensor(f"encopt/x_{tag}", (2, 3, size, size))
+    y, _ = O.encoder_forward(x0, sd, prefix="", training=False, padding=pad, use_batchnorm=bn)
+    close(y, g[f"enc_{tag}_y_eval"])
+    for key in sd:
+        if sd[key].dtype.is_floating_point and "running" not in key:
+            sd[key].requires_grad_(True)
+    x = x0.clone().requires_grad_(True)
+    y, upd = O.encoder_forward(x, sd, prefix="", training=True, padding=pad, use_batchnorm=bn)
+    close(y, g[f"enc_{tag}_y"])
+    (y * G.gold_tensor(f"encopt/gy_{tag}", tuple(y.shape))).sum().backward()
+    close_robust(x.grad, g[f"enc_{tag}_gx"], 2e-5)
+    for key, v in upd.items():
+        if "running" in key:
+            close(v, g[f"enc_{tag}_buf_{key}"])
+    for key in sd:
+        if sd[key].requires_grad:
+            close(sd[key].grad, g[f"enc_{tag}_g_{key}"], 1e-4)
+
+
+def test_discriminator_three_input_channels():
+    """PatchDiscriminator(input_channels=3) (src/model/gan.py:10,25)."""
+    g = golden("options")
+    sd = gstate(disc_shapes(16, 3), "disc3")
+    for key in sd:
+        if sd[key].dtype.is_floating_point and "running" not in key:
+            sd[key].requires_grad_(True)
+    x = G.gold_tensor("disc3/x", (2, 3, 50, 50)).requires_grad_(True)
+    y, upd = O.discriminator_forward(x, sd)
+    close(y, g["disc3_y"], 2e-5)
+    (y * G.gold_tensor("disc3/gy", tuple(y.shape))).sum().backward()
+    close_robust(x.grad, g["disc3_gx"], 1e-4)
+    for key, v in upd.items():
+        if "running" in key:
+            close(v, g[f"disc3_buf_{key}"])
+    for key in sd:
+        if sd[key].requires_grad and key not in ("model.2.0.bias", "model.3.0.bias", "model.4.0.bias"):
+            close(sd[key].grad, g[f"disc3_g_{key}"], 1e-3)
