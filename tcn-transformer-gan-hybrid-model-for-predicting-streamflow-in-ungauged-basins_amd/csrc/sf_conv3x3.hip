@@ -43,11 +43,11 @@ std::atomic<unsigned> g_launches{0};     // hands out the queue slots of this fi
 // diagnostic build only (tools/conv_stamps.py): shader-clock stamps of wave 0 of every workgroup
 // around the barrier, the stage and the epilogue of its first STAMP_STEPS pipeline steps
 constexpr int STAMP_STEPS = 48;
-__device__ unsigned long long g_stamps[256 * STAMP_STEPS * 4];
+__device__ unsigned long long g_stamps[256 * STAMP_STEPS * 8];
 #define SF_STAMP(slot)                                                                              \
     do {                                                                                            \
         if (tid == 0 && stamp_step < STAMP_STEPS)                                                   \
-            g_stamps[(blockIdx.x * STAMP_STEPS + stamp_step) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); \
+            g_stamps[(blockIdx.x * STAMP_STEPS + stamp_step) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define SF_STAMP(slot) do { } while (0)
@@ -295,8 +295,18 @@ struct ItemPos {
 // RES (C == 2 stages, K <= KT): the weights of both stages are copied once and stay in LDS for
 // the whole kernel -- [stage 0 weights][stage 1 weights][patch buffer 0][patch buffer 1], the
 // same 152 KB -- so an item fetches its two patch stages only: half the bytes per MFMA.
-template <int KT, int CK, bool RES>
+// EPI fixes the epilogue at compile time (the run-time flags cost the generic epilogue a few hundred
+// scalar branches per item, a fifth of the kernel): 0 = whatever the parameters say; 1 = plain bf16
+// output, no bias / activation / mask, K a multiple of KT and of the 16-byte groups; 2 (RES) = bias +
+// ReLU + the fused 1x1 projection, whole-line stores; 3 (RES) = ReLU mask of `aux`, whole-line stores.
+// The host picks the variant whose conditions the call meets (launch3_dma).
+template <int KT, int CK, bool RES, int EPI>
 __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
+    constexpr bool SP = EPI != 0;
+    static_assert(EPI < 2 || RES, "epilogues 2 and 3 belong to the resident shape");
+    const bool e_bias = SP ? EPI == 2 : p.bias != nullptr;
+    const int e_act = SP ? (EPI == 2 ? SF_ACT_RELU : SF_ACT_NONE) : p.act;
+    const int e_aux = SP ? (EPI == 3 ? 1 : 0) : p.aux_mode;
     using Cf = DCfg<KT, CK>;
     constexpr int ROWB = Cf::ROWB, SLOTS = Cf::SLOTS, RPP = Cf::RPP, MT = Cf::MT, KS = Cf::KS, NPOS = Cf::NPOS;
     constexpr int D_WIMG = Cf::WIMG, D_BUF = Cf::BUF, D_WJOBS = Cf::WJOBS, D_PJOBS = Cf::PJOBS;
@@ -413,6 +423,16 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         prow[c] = (ly + 1) * PW + lx + 1;
         lyx[c] = (ly << 16) | lx;
     }
+    // whole-line epilogue (resident shape): the pixel whose 16-byte piece this lane stores, per pixel tile and pass
+    int st_lyx[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave * 64 + c * 32 + (lane >> 3) + 8 * j;
+            const int ly = q / p.TW;
+            st_lyx[c][j] = (RES || EPI == 1) ? (ly << 16) | (q - ly * p.TW) : 0;
+        }
     // byte offset of the lane's B fragment in the patch image for tap t, reduction step 0
     // (step 1, 64-byte rows only, is the same offset ^ 32): tile-invariant, so computed once
     int pa[2][9];
@@ -494,6 +514,30 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // 16-byte pieces of 32 pixels, and the wave stores them back out as whole lines, 8 lanes per
     // pixel, with streaming (non-temporal) stores: the output then neither leaves partial lines for L2
     // to merge nor pushes the input lines of the next stages out of it.
+    // The wide plain variant does the same per 64-channel half of its 128 output channels, through a
+    // slice region of its own behind the stage buffers (no barrier: the slices are private to a wave).
+    constexpr bool LINES = RES || EPI == 1;
+    auto flush_lines = [&](const ItemPos& it, char* lines, int c, int half) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int G = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pr = (lane >> 3) + 8 * j;                   // pixel row of the slice
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lines + wave * 4096 + pr * 128 + ((G ^ ((pr >> 1) & 7)) << 4));
+            const int q = wave * 64 + c * 32 + pr;
+            const int ly = st_lyx[c][j] >> 16, lx = st_lyx[c][j] & 0xffff;   // q / TW, q % TW: tile-invariant
+            const int gy = it.y0 + ly, gx = it.x0 + lx;
+            if (q < TP && gy < p.H && gx < p.W)
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.out) +
+                                            (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo + it.k0 + half * 64 + G * 8));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                          // the slice is rewritten for the next pieces
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto epilogue = [&](const ItemPos& it, char* lines) {
         long long pixoff[2], pixidx[2];
         bool pv[2];
@@ -514,20 +558,20 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         // 4-channel halves of every 8-channel group of the same pixel; one v_permlane32_swap per
         // dword regroups them so that the low lane owns all 8 channels of the even group and the
         // high lane those of the odd group (stores), and back (mask loads).
-        const bool wide = (p.K & 7) == 0 && (p.ldo & 7) == 0;
-        const bool wide_out = wide && p.out_dtype == SF_BF16;
+        const bool wide = SP || ((p.K & 7) == 0 && (p.ldo & 7) == 0);
+        const bool wide_out = SP || (wide && p.out_dtype == SF_BF16);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             // mask operand of this pixel tile, all loads first
             uint2 axr[MT][4];
-            if (p.aux_mode && wide) {
+            if (e_aux && wide) {
                 uint4 ax4[MT][2];
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
-                        const bf16* src = (pv[c] && k < p.K) ? p.aux + pixoff[c] + k : zsrc;
+                        const bf16* src = (pv[c] && (SP || k < p.K)) ? p.aux + pixoff[c] + k : zsrc;
                         ax4[a][gp] = *reinterpret_cast<const uint4*>(src);
                     }
 #pragma unroll
@@ -540,13 +584,13 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                         axr[a][2 * gp] = make_uint2(s0[0], s1[0]);
                         axr[a][2 * gp + 1] = make_uint2(s0[1], s1[1]);
                     }
-            } else if (p.aux_mode) {
+            } else if (e_aux) {
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int k = it.k0 + a * 32 + 8 * g + 4 * h;
-                        const bf16* src = (pv[c] && k < p.K) ? p.aux + pixoff[c] + k : zsrc;
+                        const bf16* src = (pv[c] && (SP || k < p.K)) ? p.aux + pixoff[c] + k : zsrc;
                         axr[a][g] = *reinterpret_cast<const uint2*>(src);
                     }
             }
@@ -555,19 +599,19 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                 const int k = it.k0 + a * 32 + 8 * g + 4 * h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[a][c][4 * g + e];
-                if (p.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(sbias + (k < p.K ? k : 0));
+                if (e_bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(sbias + ((SP || k < p.K) ? k : 0));
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
-                if (p.act == SF_ACT_RELU) {
+                if (e_act == SF_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // keeps NaN, like torch.relu
-                } else if (p.act == SF_ACT_LRELU) {
+                } else if (e_act == SF_ACT_LRELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
                 }
-                if (p.aux_mode) {
-                    const float neg = p.aux_mode == 1 ? 0.f : 0.2f;
+                if (e_aux) {
+                    const float neg = e_aux == 1 ? 0.f : 0.2f;
                     const unsigned u0 = axr[a][g].x, u1 = axr[a][g].y;
                     // bf16 > 0  <=>  sign clear and not zero
                     const bool p0 = !(u0 & 0x8000u) && (u0 & 0x7fffu), p1 = !(u0 & 0x80000000u) && (u0 & 0x7fff0000u);
@@ -576,7 +620,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                     v[2] = p2 ? v[2] : neg * v[2]; v[3] = p3 ? v[3] : neg * v[3];
                 }
             };
-            const bool dot = RES && p.dot_out != nullptr;      // (host: bf16 output in 16-byte groups, k0 = 0)
+            const bool dot = SP ? EPI == 2 : (RES && p.dot_out != nullptr);      // (host: bf16 output in 16-byte groups, k0 = 0)
             float dsum = 0.f;
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -601,12 +645,13 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                         const auto s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
                         const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
-                        if (RES && lines) {
-                            // row r of the wave's slice, 16-byte slot (channel group) XOR (r >> 1) & 7
-                            const int G = a * 4 + 2 * gp + h;
+                        if (LINES && lines) {
+                            // row r of the wave's slice, 16-byte slot (channel group of the 64-channel half) XOR (r >> 1) & 7
+                            const int G = (a & 1) * 4 + 2 * gp + h;
                             *reinterpret_cast<uint4*>(lines + wave * 4096 + r * 128 + ((G ^ ((r >> 1) & 7)) << 4)) =
                                 make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                        } else if (pv[c] && k < p.K)
+                            if ((a & 1) && gp == 1) flush_lines(it, lines, c, a >> 1);   // 64 channels = one line per pixel
+                        } else if (pv[c] && (SP || k < p.K))
                             *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.out) + pixoff[c] + k) =
                                 make_uint4(s0[0], s1[0], s0[1], s1[1]);
                     } else {
@@ -632,40 +677,19 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                 dsum += __shfl_xor(dsum, 32, 64);        // the other 32 channels of the pixel
                 if (h == 0 && pv[c]) p.dot_out[pixidx[c]] = dsum + p.dot_b[0];
             }
-            if (RES && lines && wide_out) {
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int G = lane & 7;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int pr = (lane >> 3) + 8 * j;                   // pixel row of the slice
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(lines + wave * 4096 + pr * 128 + ((G ^ ((pr >> 1) & 7)) << 4));
-                    const int q = wave * 64 + c * 32 + pr;
-                    const int ly = q / p.TW, lx = q - ly * p.TW;
-                    const int gy = it.y0 + ly, gx = it.x0 + lx;
-                    if (q < TP && gy < p.H && gx < p.W)
-                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.out) +
-                                                    (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo + G * 8));
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();                          // the slice is rewritten for the next 32 pixels
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
         }
     };
 
     // ---- stage loop: cur = stage being computed, nxt = stage being copied
-    if (p.bias) {
+    if (e_bias) {
         float* sb = reinterpret_cast<float*>(smd + 2 * D_BUF);
         for (int i = tid; i < D_BIAS_MAX; i += D_NT) sb[i] = i < p.K ? p.bias[i] : 0.f;
     }
-    if (RES && p.dot_out && tid < 64)
+    if (RES && (SP ? EPI == 2 : p.dot_out != nullptr) && tid < 64)
         reinterpret_cast<float*>(smd + 2 * D_BUF)[D_BIAS_MAX + tid] = tid < p.K ? p.dot_w[tid] : 0.f;
     // whole-line streaming stores: bf16 output rows of exactly 64 channels (one 128-byte line each)
-    const bool line_stores = RES && p.K == 64 && p.ldo == 64 && p.out_dtype == SF_BF16 &&
-                             (reinterpret_cast<uintptr_t>(p.out) & 127) == 0;
+    const bool line_stores = EPI >= 2 || (RES && p.K == 64 && p.ldo == 64 && p.out_dtype == SF_BF16 &&
+                                          (reinterpret_cast<uintptr_t>(p.out) & 127) == 0);
 #ifdef SF_CONV3_STAMPS
     int stamp_step = 0;
 #endif
@@ -718,8 +742,12 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
             if (RES && line_stores) {
                 __syncthreads();          // every wave is done reading the patch the pieces are parked in
                 lines = const_cast<char*>(cur_buf);
+            } else if (EPI == 1) {
+                lines = smd + 2 * D_BUF + sizeof(float) * D_BIAS_MAX;
             }
+            SF_STAMP(4);
             epilogue(cur, lines);
+            SF_STAMP(5);
             zero_acc();
         }
         cur = nxt;
@@ -767,9 +795,12 @@ extern "C" int sf_conv3x3_read_stamps(unsigned long long* out, int n) {
 
 // (plain kernels around the templated body: hipcc does not emit the host stub of a kernel
 // template whose body holds these buffer-resource lambdas)
-__global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) { conv3_dma_body<64, 32, false>(p); }
-__global__ __launch_bounds__(D_NT, 2) void conv3_dma_res_kernel(C3DParams p) { conv3_dma_body<64, 32, true>(p); }
-__global__ __launch_bounds__(D_NT, 2) void conv3_dma_wide_kernel(C3DParams p) { conv3_dma_body<128, 16, false>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_kernel(C3DParams p) { conv3_dma_body<64, 32, false, 0>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_res_any_kernel(C3DParams p) { conv3_dma_body<64, 32, true, 0>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_res_kernel(C3DParams p) { conv3_dma_body<64, 32, true, 2>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_res_mask_kernel(C3DParams p) { conv3_dma_body<64, 32, true, 3>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_wide_any_kernel(C3DParams p) { conv3_dma_body<128, 16, false, 0>(p); }
+__global__ __launch_bounds__(D_NT, 2) void conv3_dma_wide_kernel(C3DParams p) { conv3_dma_body<128, 16, false, 1>(p); }
 
 // tile of the persistent kernel: at most D_TP pixels, patch at most D_PP; fewest tiles, least halo
 void pick_tile_dma(int H, int W, int* th, int* tw) {
@@ -807,16 +838,33 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
     p.ntiles = (int)ntiles;
     p.ktiles = (p.K + KT - 1) / KT;
     p.nchunks = (p.C + CK - 1) / CK;
-    const size_t lds = 2 * (size_t)Cf::BUF + sizeof(float) * D_BIAS_MAX + (RES ? sizeof(float) * 64 : 0);
-    void (*kern)(C3DParams) = RES ? &conv3_dma_res_kernel : KT == 64 ? &conv3_dma_kernel : &conv3_dma_wide_kernel;
-    static DeviceOnce attr_set;
-    if (!attr_set.done()) {
+    const size_t lds_base = 2 * (size_t)Cf::BUF + sizeof(float) * D_BIAS_MAX + (RES ? sizeof(float) * 64 : 0);
+    // the epilogue variant whose fixed conditions this call meets (see conv3_dma_body)
+    const bool bf16_groups = p.out_dtype == SF_BF16 && (p.K & 7) == 0 && (p.ldo & 7) == 0;
+    const bool lines = RES && p.K == 64 && p.ldo == 64 && p.out_dtype == SF_BF16 &&
+                       (reinterpret_cast<uintptr_t>(p.out) & 127) == 0;
+    int epi = 0;
+    if (!RES && KT == 128 && bf16_groups && p.K % KT == 0 && !p.bias && p.act == SF_ACT_NONE && !p.aux_mode &&
+        p.ldo % 64 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 127) == 0)
+        epi = 1;
+    if (RES && lines && p.bias && p.act == SF_ACT_RELU && !p.aux_mode && p.dot_out) epi = 2;
+    if (RES && lines && !p.bias && p.act == SF_ACT_NONE && p.aux_mode == 1 && !p.dot_out) epi = 3;
+#ifdef SF_CONV3_GENERIC_EPILOGUE
+    epi = 0;     // diagnostic build (A/B timing): every call on the run-time epilogue
+#endif
+    void (*kern)(C3DParams) = RES ? (epi == 2 ? &conv3_dma_res_kernel : epi == 3 ? &conv3_dma_res_mask_kernel : &conv3_dma_res_any_kernel)
+                              : KT == 64 ? &conv3_dma_kernel
+                                         : (epi == 1 ? &conv3_dma_wide_kernel : &conv3_dma_wide_any_kernel);
+    const size_t lds = lds_base + (epi == 1 ? 8 * 4096 : 0);      // + the eight waves' line slices
+    static DeviceOnce attr_set[4];
+    DeviceOnce& once = attr_set[epi];
+    if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("sf_conv3x3: cannot raise the dynamic LDS limit to %zu bytes", lds);
             return SF_ELAUNCH;
         }
-        attr_set.mark();
+        once.mark();
     }
     long long items = ntiles * p.ktiles;
     long long grid = (items + 7) / 8 * 8;

@@ -59,8 +59,15 @@ struct ItemPos {
     int n, y0, x0, k0, cls;
 };
 
-template <bool DGRAD>
+// EPI fixes the epilogue's options at compile time (decided by scalar branches per 8-channel group
+// they cost the run-time form a third of its time): 0 = as the parameters say; 1 = bias only (the
+// PatchGAN forward convs, BatchNorm follows); 2 = nothing (data gradient); 3 = LeakyReLU mask of
+// `aux` (data gradient behind the first layer's activation).
+template <bool DGRAD, int EPI>
 __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
+    const bool e_bias = EPI ? EPI == 1 : p.bias != nullptr;
+    const int e_act = EPI ? SF_ACT_NONE : p.act;
+    const int e_aux = EPI ? (EPI == 3 ? 2 : 0) : p.aux_mode;
     extern __shared__ __attribute__((aligned(16))) char smd[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -232,7 +239,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             uint2 axr[MT][4];
-            if (p.aux_mode) {
+            if (e_aux) {
                 uint4 ax4[MT][2];
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
@@ -258,19 +265,19 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
                 const int k = it.k0 + a * 32 + 8 * g + 4 * h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[a][c][4 * g + e];
-                if (p.bias) {
+                if (e_bias) {
                     const float4 bv = *reinterpret_cast<const float4*>(sbias + (k < p.K ? k : 0));
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
-                if (p.act == SF_ACT_RELU) {
+                if (e_act == SF_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
-                } else if (p.act == SF_ACT_LRELU) {
+                } else if (e_act == SF_ACT_LRELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
                 }
-                if (p.aux_mode) {
-                    const float neg = p.aux_mode == 1 ? 0.f : 0.2f;
+                if (e_aux) {
+                    const float neg = e_aux == 1 ? 0.f : 0.2f;
                     const unsigned u0 = axr[a][g].x, u1 = axr[a][g].y;
                     const bool p0 = !(u0 & 0x8000u) && (u0 & 0x7fffu), p1 = !(u0 & 0x80000000u) && (u0 & 0x7fff0000u);
                     const bool p2 = !(u1 & 0x8000u) && (u1 & 0x7fffu), p3 = !(u1 & 0x80000000u) && (u1 & 0x7fff0000u);
@@ -297,7 +304,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     };
 
     // ---- stage loop: cur = stage being computed, nxt = stage being copied
-    if (p.bias) {
+    if (e_bias) {
         float* sb = reinterpret_cast<float*>(smd + 2 * BUF);
         for (int i = tid; i < S_BIAS_MAX; i += S_NT) sb[i] = i < p.K ? p.bias[i] : 0.f;
     }
@@ -365,8 +372,11 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     }
 }
 
-__global__ __launch_bounds__(S_NT, 2) void conv_s2_fwd_kernel(S2Params p) { conv_s2_body<false>(p); }
-__global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_kernel(S2Params p) { conv_s2_body<true>(p); }
+__global__ __launch_bounds__(S_NT, 2) void conv_s2_fwd_any_kernel(S2Params p) { conv_s2_body<false, 0>(p); }
+__global__ __launch_bounds__(S_NT, 2) void conv_s2_fwd_kernel(S2Params p) { conv_s2_body<false, 1>(p); }
+__global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_any_kernel(S2Params p) { conv_s2_body<true, 0>(p); }
+__global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_kernel(S2Params p) { conv_s2_body<true, 2>(p); }
+__global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_mask_kernel(S2Params p) { conv_s2_body<true, 3>(p); }
 
 // tile of at most S_TP pixels whose (TH+1) x (TW+1) patch fits S_PP rows: fewest tiles, least halo
 void pick_tile_s2(int H, int W, int* th, int* tw) {
@@ -455,9 +465,14 @@ extern "C" int sf_conv4x4s2(const void* in, const void* wp, const float* bias, c
     p.ktiles = (K + KT - 1) / KT;
     p.cch = C / CK;
     const size_t lds = 2 * (size_t)BUF + sizeof(float) * S_BIAS_MAX;
-    void (*kern)(S2Params) = dgrad ? &conv_s2_dgrad_kernel : &conv_s2_fwd_kernel;
-    static DeviceOnce attr_set[2];
-    DeviceOnce& once = attr_set[dgrad ? 1 : 0];
+    // the epilogue variant whose fixed options this call uses (see conv_s2_body)
+    int vi = dgrad ? 2 : 0;
+    void (*kern)(S2Params) = dgrad ? &conv_s2_dgrad_any_kernel : &conv_s2_fwd_any_kernel;
+    if (!dgrad && bias && act == SF_ACT_NONE && !aux_mode) { kern = &conv_s2_fwd_kernel; vi = 1; }
+    if (dgrad && !bias && act == SF_ACT_NONE && !aux_mode) { kern = &conv_s2_dgrad_kernel; vi = 3; }
+    if (dgrad && !bias && act == SF_ACT_NONE && aux_mode == 2) { kern = &conv_s2_dgrad_mask_kernel; vi = 4; }
+    static DeviceOnce attr_set[5];
+    DeviceOnce& once = attr_set[vi];
     if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {

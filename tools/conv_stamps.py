@@ -25,10 +25,10 @@ for _ in range(3):
     ops.conv3x3(x, ws, out, K)
 torch.cuda.synchronize()
 STEPS = 48
-buf = np.zeros(256 * STEPS * 4, dtype=np.uint64)
+buf = np.zeros(256 * STEPS * 8, dtype=np.uint64)
 rc = ops.lib().sf_conv3x3_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
 assert rc == 0
-s = buf.reshape(256, STEPS, 4).astype(np.int64)
+s = buf.reshape(256, STEPS, 8).astype(np.int64)
 bar = s[:, :, 1] - s[:, :, 0]
 stage = s[:, :, 2] - s[:, :, 1]
 epi = s[:, :, 3] - s[:, :, 2]
@@ -39,6 +39,10 @@ print("  barrier wait  ", np.median(bar[:, sl]), " mean", bar[:, sl].mean())
 print("  stage (MFMA)  ", np.median(stage[:, sl]), " mean", stage[:, sl].mean())
 print("  after stage   ", np.median(epi[:, sl]), " mean", epi[:, sl].mean(), " (epilogue steps:", np.median(epi[:, sl][epi[:, sl] > 500]) if (epi[:, sl] > 500).any() else 0, ")")
 print("  step total    ", np.median(tot[:, sl]), " mean", tot[:, sl].mean())
+ep = s[:, sl, :][(s[:, sl, 4] > 0) & (s[:, sl, 5] > 0) & (epi[:, sl] > 500)]
+if len(ep):
+    print("  epilogue steps: barrier before", np.median(ep[:, 4] - ep[:, 2]), " epilogue body", np.median(ep[:, 5] - ep[:, 4]),
+          " rest", np.median(ep[:, 3] - ep[:, 5]), " whole", np.median(ep[:, 3] - ep[:, 2]))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
