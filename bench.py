@@ -138,7 +138,7 @@ def main():
     # kernel are bracketed (2 per step: the encoder's second conv and its data gradient); the other
     # MFMA kernels are timed in extra steps after it
     dom = "conv3_dma_wide_kernel"
-    other_tags = ("conv3_dma_res_kernel", "conv3_dma_kernel", "wgrad3_dma_kernel")
+    other_tags = ("conv3_dma_res_kernel", "conv3_dma_res_mask_kernel", "conv3_dma_kernel", "wgrad3_dma_kernel")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -204,7 +204,7 @@ def main():
     if rank == 0:
         # The three MFMA kernels of the 3x3 convolutions, every launch timed with HIP events on the
         # launch stream; algorithmic flops of a launch = 2 * N*H*W * Cin * Cout * 9 with the real
-        # channel counts.  conv3_dma_wide_kernel / conv3_dma_kernel / conv3_dma_res_kernel are the
+        # channel counts.  conv3_dma_wide_kernel / conv3_dma_kernel / conv3_dma_res_kernel / conv3_dma_res_mask_kernel are the
         # shapes of the persistent forward / data-gradient kernel (res: weights resident in LDS), wgrad3_dma_kernel the weight gradient (its
         # event pair also spans the small slab-reduction launch that follows it).
         n_l, ms_l, achieved = dom_stats

@@ -538,6 +538,25 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         __builtin_amdgcn_wave_barrier();                          // the slice is rewritten for the next pieces
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // Mask variant: the mask operand of an item (the 16-byte groups this lane will need) is requested
+    // before the item's last stage runs, so that the epilogue finds it in registers instead of
+    // waiting out two round trips to memory.
+    uint4 axp[2][MT][2];
+    auto aux_prefetch = [&](const ItemPos& it) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int gy = it.y0 + (lyx[c] >> 16), gx = it.x0 + (lyx[c] & 0xffff);
+            const bool ok = pin[c] && gy < p.H && gx < p.W;
+            const long long po = ok ? (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo : 0;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
+                    axp[c][a][gp] = *reinterpret_cast<const uint4*>(ok ? p.aux + po + k : zsrc);
+                }
+        }
+    };
     auto epilogue = [&](const ItemPos& it, char* lines) {
         long long pixoff[2], pixidx[2];
         bool pv[2];
@@ -570,6 +589,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
+                        if (EPI == 3) { ax4[a][gp] = axp[c][a][gp]; continue; }
                         const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
                         const bf16* src = (pv[c] && (SP || k < p.K)) ? p.aux + pixoff[c] + k : zsrc;
                         ax4[a][gp] = *reinterpret_cast<const uint4*>(src);
@@ -735,6 +755,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // one step of the pipeline; `cur_buf` holds the landed stage, `fill` takes the next copy
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
         const StageSrc ss = stage_src(nxt, nxt.q < nitems);
+        if (EPI == 3 && cur.chunk == p.nchunks - 1) aux_prefetch(cur);
         run_stage(cur_buf, fill, ss, RES ? smd + cur.chunk * D_WIMG : cur_buf);
         SF_STAMP(2);
         if (cur.chunk == p.nchunks - 1) {

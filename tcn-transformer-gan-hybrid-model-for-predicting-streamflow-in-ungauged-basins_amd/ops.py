@@ -259,7 +259,21 @@ def conv3x3(x, wp, out, K: int, dgrad: bool = False, bias=None, act=ACT_NONE, au
         if rec is None:
             # every launch of the persistent kernel, by variant (same rule as sf_conv3x3's dispatch)
             wide = K <= 1024 and (K > 64 or C % 32 != 0)
-            name = "conv3_dma_wide_kernel" if wide else ("conv3_dma_res_kernel" if C == 64 else "conv3_dma_kernel")
+            bf16_out = out.dtype == torch.bfloat16
+            if wide:      # plain bf16 output in whole lines, or the run-time epilogue
+                plain = (bias is None and act == ACT_NONE and aux_mode == 0 and bf16_out and K % 128 == 0
+                         and out.shape[-1] % 64 == 0 and out.data_ptr() % 128 == 0)
+                name = "conv3_dma_wide_kernel" if plain else "conv3_dma_wide_any_kernel"
+            elif C == 64:
+                lines = K == 64 and out.shape[-1] == 64 and bf16_out and out.data_ptr() % 128 == 0
+                if lines and bias is not None and act == ACT_RELU and aux_mode == 0 and dot is not None:
+                    name = "conv3_dma_res_kernel"
+                elif lines and bias is None and act == ACT_NONE and aux_mode == 1 and dot is None:
+                    name = "conv3_dma_res_mask_kernel"
+                else:
+                    name = "conv3_dma_res_any_kernel"
+            else:
+                name = "conv3_dma_kernel"
             rec = TIMED.get(name) if (wide or C % 32 == 0) else None
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
