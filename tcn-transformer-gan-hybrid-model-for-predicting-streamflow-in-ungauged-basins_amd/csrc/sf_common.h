@@ -159,6 +159,18 @@ struct WorkQueue {
 __device__ __forceinline__ int queue_take(WorkQueue* q, int h) {
     return __hip_atomic_fetch_add(&q->heads[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same ticket without waiting for it: the compiler turns a fetch-add on a uniform address into
+// its wave-aggregated form and reads the result back at once, which parks the calling wave (and,
+// at the next barrier, the workgroup) for the atomic's round trip once per item.  Here the ticket
+// stays in a register the compiler believes ready: the caller may only read it after a later
+// s_waitcnt vmcnt(0) of its own (the stage barrier's).  One lane calls this.
+__device__ __forceinline__ int queue_take_async(WorkQueue* q, int h) {
+    int ticket;
+    const int one = 1;
+    int* addr = &q->heads[h];
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(addr), "v"(one) : "memory");
+    return ticket;
+}
 // called once per workgroup by one lane, after the value of its last queue_take has arrived
 __device__ __forceinline__ void queue_leave(WorkQueue* q, int nheads, int nworkgroups) {
     const int old = __hip_atomic_fetch_add(&q->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

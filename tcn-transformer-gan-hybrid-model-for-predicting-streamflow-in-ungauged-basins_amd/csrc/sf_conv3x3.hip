@@ -557,6 +557,8 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                 }
         }
     };
+    // (read once: a load inside the epilogue would make every item wait out a memory round trip)
+    const float dot_b0 = (RES && (SP ? EPI == 2 : p.dot_out != nullptr)) ? p.dot_b[0] : 0.f;
     auto epilogue = [&](const ItemPos& it, char* lines) {
         long long pixoff[2], pixidx[2];
         bool pv[2];
@@ -695,7 +697,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                 }
             if (RES && dot && wide_out) {
                 dsum += __shfl_xor(dsum, 32, 64);        // the other 32 channels of the pixel
-                if (h == 0 && pv[c]) p.dot_out[pixidx[c]] = dsum + p.dot_b[0];
+                if (h == 0 && pv[c]) p.dot_out[pixidx[c]] = dsum + dot_b0;
             }
         }
     };
@@ -744,7 +746,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                 // the answer in the other slot after the next barrier (it has arrived by then)
                 it.q = __builtin_amdgcn_readfirstlane(s_next[q_par]);
                 q_par ^= 1;
-                if (tid == 0) { q_pending = nb8 + queue_take(wq, xcd); q_have = true; }
+                if (tid == 0) { q_pending = queue_take_async(wq, xcd); q_have = true; }   // read in park(), behind the next full barrier
             } else {
                 it.q += nb8;
             }
@@ -775,7 +777,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         advance(nxt);
     };
     auto park = [&]() {
-        if (dyn && tid == 0 && q_have) { s_next[q_par] = q_pending; q_have = false; }
+        if (dyn && tid == 0 && q_have) { s_next[q_par] = nb8 + q_pending; q_have = false; }
     };
     while (true) {
         // the stage's copy has landed (own vmcnt, then the barrier) and every wave is done
@@ -802,8 +804,8 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         if (cur.q >= nitems) break;
     }
     if (p.qslot >= 0 && tid == 0) {
-        // q_pending is read here so that the last take has returned before the workgroup counts as gone
-        if (q_have && q_pending < 0) return;
+        // the last take has returned before the workgroup counts as gone
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         queue_leave(wq, 8, gridDim.x);
     }
 }

@@ -332,7 +332,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
                 // the answer in the other slot after the next barrier (it has arrived by then)
                 it.q = __builtin_amdgcn_readfirstlane(s_next[q_par]);
                 q_par ^= 1;
-                if (tid == 0) { q_pending = nb8 + queue_take(wq, xcd); q_have = true; }
+                if (tid == 0) { q_pending = queue_take_async(wq, xcd); q_have = true; }   // read in park(), behind the next full barrier
             } else {
                 it.q += nb8;
             }
@@ -341,7 +341,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     };
     advance(nxt);
     auto park = [&]() {
-        if (dyn && tid == 0 && q_have) { s_next[q_par] = q_pending; q_have = false; }
+        if (dyn && tid == 0 && q_have) { s_next[q_par] = nb8 + q_pending; q_have = false; }
     };
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
         const StageSrc ss = stage_src(nxt, nxt.q < nitems);
@@ -366,8 +366,8 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
         if (cur.q >= nitems) break;
     }
     if (p.qslot >= 0 && tid == 0) {
-        // q_pending is read here so that the last take has returned before the workgroup counts as gone
-        if (q_have && q_pending < 0) return;
+        // the last take has returned before the workgroup counts as gone
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         queue_leave(wq, 8, gridDim.x);
     }
 }
