@@ -169,6 +169,12 @@ int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, 
 /* the same layout change for a bf16 NCHW source (the gradient that arrives at the encoder from the
  * bf16 Linear layer): bf16 [N,C,H,W] -> bf16 [N,H,W,Cpad], Cpad >= 64 */
 int sf_nchw_bf16_to_nhwc(const void* in, void* out, int N, int C, int H, int W, int Cpad, void* stream);
+/* sf_nchw_to_nhwc that also performs the input check of the training loop (src/train.py:193,
+ * torch.isnan(images).any() or torch.isinf(images).any()): *flag |= 1 if any element of `in` is Inf
+ * or NaN; the flag is never cleared here.  Few-channel bf16 inputs are checked inside the layout
+ * kernel (no second read of the images), other shapes by a pass of sf_nan_inf_flag. */
+int sf_nchw_to_nhwc_checked(const float* in, void* out, int dtype, int N, int C, int H, int W,
+                            int Cpad, int* flag, void* stream);
 /* NHWC (dtype, Cpad) -> NCHW f32 (first C channels). */
 int sf_nhwc_to_nchw(const void* in, int dtype, float* out, int N, int C, int H, int W, int Cpad,
                     void* stream);

@@ -61,7 +61,9 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 // time, padding channels re-read plane 0 and discard it.
 template <int CP, int CR>
 __global__ __launch_bounds__(NT) void nchw_to_nhwc_px4_kernel(const float* __restrict__ in, bf16* __restrict__ out,
-                                                              unsigned nquads, int Crun, unsigned HW) {
+                                                              unsigned nquads, int Crun, unsigned HW, int* __restrict__ flag) {
+    // flag (may be null): *flag |= 1 when a loaded element is Inf or NaN -- the input check of
+    // src/train.py:193 rides on the layout pass instead of reading the images a second time
     const int C = CR ? CR : Crun;
     const unsigned q = blockIdx.x * NT + threadIdx.x;
     if (q >= nquads) return;
@@ -72,6 +74,18 @@ __global__ __launch_bounds__(NT) void nchw_to_nhwc_px4_kernel(const float* __res
     for (int c = 0; c < CP; ++c) {
         if (CR && c >= CR) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         else v[c] = *reinterpret_cast<const float4*>(src + (size_t)(c < C ? c : 0) * HW);
+    }
+    if (flag) {
+        unsigned top = 0;       // largest |x| as bits: exponent all ones <=> Inf or NaN
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            if (CR && c >= CR) continue;
+            top = max(top, __float_as_uint(v[c].x) & 0x7fffffffu);
+            top = max(top, __float_as_uint(v[c].y) & 0x7fffffffu);
+            top = max(top, __float_as_uint(v[c].z) & 0x7fffffffu);
+            top = max(top, __float_as_uint(v[c].w) & 0x7fffffffu);
+        }
+        if (__any(top >= 0x7f800000u) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -470,8 +484,10 @@ extern "C" int sf_nchw_bf16_to_nhwc(const void* in, void* out, int N, int C, int
     return SF_OK;
 }
 
-extern "C" int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad,
-                               void* stream) {
+extern "C" int sf_nan_inf_flag(const float* x, long long n, int* flag, void* stream);
+
+static int nchw_to_nhwc_impl(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad, int* flag,
+                             void* stream) {
     SF_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "sf_nchw_to_nhwc: bad arguments");
     SF_REQUIRE(Cpad % (dtype == SF_BF16 ? 8 : 4) == 0, "sf_nchw_to_nhwc: Cpad=%d not a chunk multiple", Cpad);
     const long long npix = (long long)N * H * W;
@@ -481,15 +497,19 @@ extern "C" int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int
         const unsigned grid = (nquads + NT - 1) / NT;
         if (Cpad == 8)
             hipLaunchKernelGGL((nchw_to_nhwc_px4_kernel<8, 0>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
-                               nquads, C, (unsigned)HWi);
+                               nquads, C, (unsigned)HWi, flag);
         else if (C == 10)     // the reference's ten input bands
             hipLaunchKernelGGL((nchw_to_nhwc_px4_kernel<16, 10>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
-                               nquads, C, (unsigned)HWi);
+                               nquads, C, (unsigned)HWi, flag);
         else
             hipLaunchKernelGGL((nchw_to_nhwc_px4_kernel<16, 0>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, (bf16*)out,
-                               nquads, C, (unsigned)HWi);
+                               nquads, C, (unsigned)HWi, flag);
         SF_LAUNCH_CHECK("sf_nchw_to_nhwc");
         return SF_OK;
+    }
+    // the other layout kernels do not check: a pass of its own over the input
+    if (flag) {
+        if (int rc = sf_nan_inf_flag(in, (long long)N * C * H * W, flag, stream)) return rc;
     }
     if (Cpad >= 64) {
         const int ptiles = (HWi + 63) / 64, ctiles = (Cpad + 63) / 64;
@@ -505,6 +525,17 @@ extern "C" int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int
                                          (hipStream_t)stream, in, (T*)out, npix, C, H * W, Cpad));
     SF_LAUNCH_CHECK("sf_nchw_to_nhwc");
     return SF_OK;
+}
+
+extern "C" int sf_nchw_to_nhwc(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad,
+                               void* stream) {
+    return nchw_to_nhwc_impl(in, out, dtype, N, C, H, W, Cpad, nullptr, stream);
+}
+
+extern "C" int sf_nchw_to_nhwc_checked(const float* in, void* out, int dtype, int N, int C, int H, int W, int Cpad,
+                                       int* flag, void* stream) {
+    SF_REQUIRE(flag, "sf_nchw_to_nhwc_checked: null flag");
+    return nchw_to_nhwc_impl(in, out, dtype, N, C, H, W, Cpad, flag, stream);
 }
 
 extern "C" int sf_nhwc_to_nchw(const void* in, int dtype, float* out, int N, int C, int H, int W, int Cpad,

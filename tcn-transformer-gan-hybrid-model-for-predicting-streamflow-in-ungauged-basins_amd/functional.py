@@ -58,11 +58,13 @@ class EncoderFn(torch.autograd.Function):
     ReLU -> maxpool2 (all but last) ; adaptive average pool to 32x32 after the last layer."""
 
     @staticmethod
-    def forward(ctx, x, training, cdtype, target, *params):
+    def forward(ctx, x, training, cdtype, target, nan_flag, *params):
+        # nan_flag: None, or an int32 [1] device flag that the input layout pass sets when x holds
+        # Inf / NaN (the trainer's input check, src/train.py:193, without a pass of its own)
         L = len(params) // 5
         N, Cin, H, W = x.shape
         e = ops.epc(ops.code_of(cdtype))
-        a = ops.nchw_to_nhwc(x.contiguous(), cdtype, ops.roundup(Cin, 16 if cdtype == torch.bfloat16 else e))
+        a = ops.nchw_to_nhwc(x.contiguous(), cdtype, ops.roundup(Cin, 16 if cdtype == torch.bfloat16 else e), flag=nan_flag)
         saved = []
         h, w = H, W
         out = None
@@ -152,7 +154,7 @@ class EncoderFn(torch.autograd.Function):
                 else:
                     dx = ops.nhwc_to_nchw(da, Cin)
         ctx.saved = None
-        return (dx, None, None, None, *grads)
+        return (dx, None, None, None, None, *grads)
 
 
 class EncoderGeneralFn(torch.autograd.Function):

@@ -64,7 +64,9 @@ class CNNEncoder(nn.Module):
                     ps += [m.weight, m.bias]
         return ps
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, nan_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """nan_flag (extension, optional): an int32 [1] device tensor that is set to 1 when x holds Inf
+        or NaN -- the training loop's input check (src/train.py:193) done by the layout pass."""
         if x.dim() == 5:
             B, T, C, H, W = x.shape
             x = x.reshape(B * T, C, H, W)
@@ -73,11 +75,13 @@ class CNNEncoder(nn.Module):
             torch._foreach_add_([m.num_batches_tracked for m in self.encoder if isinstance(m, nn.BatchNorm2d)], 1)
         if (self.kernel_size, self.padding, self.use_batchnorm) != (3, 1, True):
             # options the model class never passes: gathered-GEMM convs, no specialised kernels
+            if nan_flag is not None:
+                ops.nan_inf_flag(x.contiguous().float().view(-1), nan_flag)
             return SF.EncoderGeneralFn.apply(x.float(), self.training, SF.compute_dtype(), self.target_spatial,
                                              self.kernel_size, self.padding,
                                              tuple([5 if self.use_batchnorm else 2] * self.num_layers),
                                              *self._layer_params())
-        return SF.EncoderFn.apply(x.float(), self.training, SF.compute_dtype(), self.target_spatial,
+        return SF.EncoderFn.apply(x.float(), self.training, SF.compute_dtype(), self.target_spatial, nan_flag,
                                   *self._layer_params())
 
     def get_output_channels(self) -> int:
@@ -246,10 +250,11 @@ class StreamflowPredictionModel(nn.Module):
         self.encoded_h, self.encoded_w, self.cnn_out_channels = enc_h, enc_w, cnn_out
         self.decoder = SimpleUpsamplingDecoder(cnn_out, self.output_height, self.output_width, hidden_channels=64)
 
-    def forward(self, images: torch.Tensor) -> torch.Tensor:
+    def forward(self, images: torch.Tensor, nan_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """nan_flag: see CNNEncoder.forward (an extension; the reference's forward takes images only)."""
         _need_cuda(images, "StreamflowPredictionModel")
         B, T, C, H, W = images.shape
-        encoded = self.cnn_encoder(images.reshape(B * T, C, H, W))
+        encoded = self.cnn_encoder(images.reshape(B * T, C, H, W), nan_flag=nan_flag)
         _, oc, he, we = encoded.shape
         t_out = self.temporal_module(encoded.reshape(B, T, -1))
         sp = SF.linear(t_out, self.temporal_to_spatial, SF.compute_dtype())

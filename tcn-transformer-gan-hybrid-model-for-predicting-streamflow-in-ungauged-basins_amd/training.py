@@ -348,9 +348,9 @@ class Trainer:
             self._set_d_requires_grad(d_live and not merge_d)
         images = images.to(self.device, non_blocking=True)
         output_image = output_image.to(self.device, non_blocking=True)
-        ops.nan_inf_flag(images.contiguous().float().view(-1), self.nan_flags[_FLAG_IMAGES:_FLAG_IMAGES + 1])
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp):
-            pred = self.model(images)
+            # the input check of src/train.py:193 rides on the encoder's layout pass
+            pred = self.model(images, nan_flag=self.nan_flags[_FLAG_IMAGES:_FLAG_IMAGES + 1])
             ops.nan_inf_flag(pred.view(-1), self.nan_flags[_FLAG_PRED:_FLAG_PRED + 1])
             ld = self.loss_fn(pred, output_image, station_positions, station_runoffs)
             loss_g = ld["total"]

@@ -874,6 +874,33 @@ def test_discriminator_three_input_channels_f32(sf):
         sf.set_compute_dtype(None)
 
 
+def test_layout_pass_with_input_check(sf):
+    """sf_nchw_to_nhwc_checked (the input Inf / NaN check of src/train.py:193 done by the layout
+    pass): same output as sf_nchw_to_nhwc bit for bit; the flag stays 0 on finite input (large and
+    denormal values included) and is set by a single NaN, +Inf or -Inf anywhere, in the few-channel
+    bf16 kernel (10 and 3 channels), in the shapes that take the other layout kernels, and in f32."""
+    ops = sf.ops
+    torch.manual_seed(5)
+    for (N, C, H, W, dt, cpad) in [(3, 10, 40, 36, torch.bfloat16, 16), (2, 3, 24, 20, torch.bfloat16, 16),
+                                   (2, 5, 16, 16, torch.bfloat16, 8), (2, 70, 9, 11, torch.bfloat16, 72),
+                                   (2, 10, 17, 13, torch.bfloat16, 16), (2, 10, 12, 12, torch.float32, 12)]:
+        x = torch.randn(N, C, H, W, device=DEV)
+        x[0, 0, 0, 0], x[-1, -1, -1, -1], x[0, C // 2, 1, 2] = 3.0e38, -3.0e38, 1.0e-42
+        want = ops.nchw_to_nhwc(x, dt, cpad)
+        flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+        got = ops.nchw_to_nhwc(x, dt, cpad, flag=flag)
+        assert torch.equal(got.view(torch.int16 if dt == torch.bfloat16 else torch.int32),
+                           want.view(torch.int16 if dt == torch.bfloat16 else torch.int32))
+        assert int(flag) == 0, (N, C, H, W, dt)
+        for bad, where in ((float("nan"), (N - 1, C - 1, H - 1, W - 1)), (float("inf"), (0, 0, 0, 0)),
+                           (float("-inf"), (N // 2, C // 2, H // 2, W // 3))):
+            xb = x.clone()
+            xb[where] = bad
+            flag.zero_()
+            ops.nchw_to_nhwc(xb, dt, cpad, flag=flag)
+            assert int(flag) == 1, (bad, N, C, H, W, dt)
+
+
 def test_colsum_f32_shapes(sf):
     """Bias-gradient column sums of the two Linear layers (short and very wide, tall and narrow),
     odd sizes and a single element, against a float64 sum."""
