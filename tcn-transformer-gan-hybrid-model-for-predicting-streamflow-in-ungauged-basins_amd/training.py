@@ -225,6 +225,7 @@ class Trainer:
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.world = dist.get_world_size() if self.distributed else 1
         self.nan_flags = torch.zeros(4, device=self.device, dtype=torch.int32)
+        self._one = torch.ones(1, device=self.device)      # the 'real' label of the adversarial losses
         self.found_inf = torch.zeros(2, device=self.device, dtype=torch.int32)    # generator / discriminator gradients
         self._pending: List = []
         self._reduce_now = False
@@ -357,12 +358,12 @@ class Trainer:
             if self.use_gan:
                 pred_fake = self.discriminator(pred, keep_record=d_batch)
                 fake_record = self.discriminator.last_record
-                g_gan = self.gan_loss_fn.gan_loss(pred_fake, torch.ones(1, device=self.device))
+                g_gan = self.gan_loss_fn.gan_loss(pred_fake, self._one)
                 loss_g = loss_g + self.gan_weight * g_gan
                 ld["gan_g"] = g_gan
                 ld["total"] = loss_g
             ops.nan_inf_flag(loss_g.detach().reshape(1), self.nan_flags[_FLAG_LOSS:_FLAG_LOSS + 1])
-        (loss_g / self.accum).backward()
+        (loss_g / self.accum if self.accum != 1 else loss_g).backward()      # (x / 1 is x: two launches less)
         # The generator's update needs nothing from the discriminator pass below (which works on
         # pred.detach() and never reads a generator parameter), so it is issued first: its large
         # kernels keep the GPU busy while the host works through the many small launches of the
@@ -387,9 +388,9 @@ class Trainer:
                 ld["gan_d"] = loss_d
                 back_d = loss_d
                 if merge_d:
-                    back_d = loss_d + self.gan_weight * self.gan_loss_fn.gan_loss(pred_fake_d, torch.ones(1, device=self.device))
+                    back_d = loss_d + self.gan_weight * self.gan_loss_fn.gan_loss(pred_fake_d, self._one)
             if d_live:
-                (back_d / self.accum).backward()
+                (back_d / self.accum if self.accum != 1 else back_d).backward()
         if stepping:
             if d_batch:
                 self.opt_d.gather()
