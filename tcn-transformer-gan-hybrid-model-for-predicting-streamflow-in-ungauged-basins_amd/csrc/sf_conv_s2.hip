@@ -63,7 +63,10 @@ struct ItemPos {
 // they cost the run-time form a third of its time): 0 = as the parameters say; 1 = bias only (the
 // PatchGAN forward convs, BatchNorm follows); 2 = nothing (data gradient); 3 = LeakyReLU mask of
 // `aux` (data gradient behind the first layer's activation).
-template <bool DGRAD, int EPI>
+// MTU: 32-channel output tiles an item really has (4, or 2 when the layer has at most 64 output
+// channels: the MFMAs, fragment reads and epilogue of the zero half are skipped, and so are the copy
+// pieces of the weight image's zero rows).
+template <bool DGRAD, int EPI, int MTU = MT>
 __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     const bool e_bias = EPI ? EPI == 1 : p.bias != nullptr;
     const int e_act = EPI ? SF_ACT_NONE : p.act;
@@ -143,7 +146,9 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     auto issue_piece = [&](const StageSrc& ss, char* buf, int j) {
         if (j < NWJ) {
             const int job = wave + 8 * j;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(buf + job * 1024), 16, w_rel[j], 0, 0, 0);
+            // a piece is 32 rows of the image: rows t * 128 + k, so pieces 4 t + 2, 4 t + 3 hold k >= 64
+            if (MTU == MT || (job & 3) < 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(buf + job * 1024), 16, w_rel[j], 0, 0, 0);
         } else if (j < NPIECE) {
             const int i = j - NWJ, job = wave + 8 * i;
             if (PJOBS % 8 == 0 || job < PJOBS) {
@@ -174,10 +179,10 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     }
     const int aLane = r * ROWB + ((h ^ swz(r)) << 4);      // weights: row t*KT + a*32 + r (swz depends on r only)
 
-    f32x16 acc[MT][2];
+    f32x16 acc[MTU][2];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < MTU; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -190,11 +195,11 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     auto run_stage = [&](const char* __restrict__ cur, char* __restrict__ fill, const StageSrc& ss) {
         const char* wl = cur + aLane;
         const char* pl = cur + WIMG;
-        bf16x8 fa[2][MT], fb[2][2];
+        bf16x8 fa[2][MTU], fb[2][2];
         auto issue = [&](int i) {
             const int s = i & 1;
 #pragma unroll
-            for (int a = 0; a < MT; ++a) fa[s][a] = *reinterpret_cast<const bf16x8*>(wl + (i * KT + a * 32) * ROWB);
+            for (int a = 0; a < MTU; ++a) fa[s][a] = *reinterpret_cast<const bf16x8*>(wl + (i * KT + a * 32) * ROWB);
 #pragma unroll
             for (int c = 0; c < 2; ++c) fb[s][c] = *reinterpret_cast<const bf16x8*>(pl + pa[c][i]);
         };
@@ -206,7 +211,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
             for (int j = i * PPP; j < (i + 1) * PPP; ++j) issue_piece(ss, fill, j);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+            for (int a = 0; a < MTU; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][a], fb[i & 1][c], acc[a][c], 0, 0, 0);
@@ -238,11 +243,11 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
         };
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            uint2 axr[MT][4];
+            uint2 axr[MTU][4];
             if (e_aux) {
-                uint4 ax4[MT][2];
+                uint4 ax4[MTU][2];
 #pragma unroll
-                for (int a = 0; a < MT; ++a)
+                for (int a = 0; a < MTU; ++a)
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
@@ -251,7 +256,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
                         ax4[a][gp] = *reinterpret_cast<const uint4*>(src);
                     }
 #pragma unroll
-                for (int a = 0; a < MT; ++a)
+                for (int a = 0; a < MTU; ++a)
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         const uint4 d = ax4[a][gp];
@@ -286,7 +291,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
                 }
             };
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+            for (int a = 0; a < MTU; ++a)
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     float v0[4], v1[4];
@@ -377,6 +382,9 @@ __global__ __launch_bounds__(S_NT, 2) void conv_s2_fwd_kernel(S2Params p) { conv
 __global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_any_kernel(S2Params p) { conv_s2_body<true, 0>(p); }
 __global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_kernel(S2Params p) { conv_s2_body<true, 2>(p); }
 __global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_mask_kernel(S2Params p) { conv_s2_body<true, 3>(p); }
+__global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_mask64_kernel(S2Params p) { conv_s2_body<true, 3, 2>(p); }
+__global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_any64_kernel(S2Params p) { conv_s2_body<true, 0, 2>(p); }
+__global__ __launch_bounds__(S_NT, 2) void conv_s2_fwd_any64_kernel(S2Params p) { conv_s2_body<false, 0, 2>(p); }
 
 // tile of at most S_TP pixels whose (TH+1) x (TW+1) patch fits S_PP rows: fewest tiles, least halo
 void pick_tile_s2(int H, int W, int* th, int* tw) {
@@ -471,7 +479,12 @@ extern "C" int sf_conv4x4s2(const void* in, const void* wp, const float* bias, c
     if (!dgrad && bias && act == SF_ACT_NONE && !aux_mode) { kern = &conv_s2_fwd_kernel; vi = 1; }
     if (dgrad && !bias && act == SF_ACT_NONE && !aux_mode) { kern = &conv_s2_dgrad_kernel; vi = 3; }
     if (dgrad && !bias && act == SF_ACT_NONE && aux_mode == 2) { kern = &conv_s2_dgrad_mask_kernel; vi = 4; }
-    static DeviceOnce attr_set[5];
+    if (K <= 64) {      // half-width items (conv_s2_body's MTU = 2)
+        if (vi == 4) { kern = &conv_s2_dgrad_mask64_kernel; vi = 5; }
+        else if (dgrad) { kern = &conv_s2_dgrad_any64_kernel; vi = 6; }
+        else { kern = &conv_s2_fwd_any64_kernel; vi = 7; }
+    }
+    static DeviceOnce attr_set[8];
     DeviceOnce& once = attr_set[vi];
     if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
