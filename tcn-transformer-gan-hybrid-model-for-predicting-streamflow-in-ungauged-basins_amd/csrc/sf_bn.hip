@@ -639,7 +639,8 @@ template <int EPC> struct PosChunk;
 template <> struct PosChunk<8> {
     using Raw = uint4;
     static __device__ __forceinline__ Raw pack(const int* c) {
-        return make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
+        auto two = [](int lo, int hi) { return (unsigned)lo | ((unsigned)hi << 16); };     // counts are at most 65535
+        return make_uint4(two(c[0], c[1]), two(c[2], c[3]), two(c[4], c[5]), two(c[6], c[7]));
     }
     static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
         f[0] = (float)(r.x & 0xffffu); f[1] = (float)(r.x >> 16); f[2] = (float)(r.y & 0xffffu); f[3] = (float)(r.y >> 16);
@@ -648,7 +649,9 @@ template <> struct PosChunk<8> {
 };
 template <> struct PosChunk<4> {
     using Raw = uint2;
-    static __device__ __forceinline__ Raw pack(const int* c) { return make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16)); }
+    static __device__ __forceinline__ Raw pack(const int* c) {
+        return make_uint2((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16));
+    }
     static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
         f[0] = (float)(r.x & 0xffffu); f[1] = (float)(r.x >> 16); f[2] = (float)(r.y & 0xffffu); f[3] = (float)(r.y >> 16);
     }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 
 typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -145,9 +146,10 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // Work queues of the persistent kernels.  A launch owns one slot of a small pool of counter sets
 // (a file-scope __device__ array of the kernel's translation unit, zero at load): heads[] are
 // bumped by workgroups asking for their next item, `done` counts workgroups that have left; the
-// last one to leave zeroes the slot again, so nothing has to be cleared between launches.  The
-// host hands out slots round-robin: a slot is reused only after SF_QUEUE_SLOTS - 1 later launches
-// of that kernel family, by which time stream order has long retired its earlier user.
+// last one to leave zeroes the slot again, so nothing has to be cleared between launches.  Slots
+// belong to streams (StreamSlots below): launches on one stream run one after the other, so a slot
+// never has two users at a time however many launches are queued, and launches on different
+// streams (or from different host threads) never share one.
 #define SF_QUEUE_SLOTS 64
 #define SF_QUEUE_HEADS 124
 struct WorkQueue {
@@ -161,14 +163,23 @@ __device__ __forceinline__ int queue_take(WorkQueue* q, int h) {
 }
 // The same ticket without waiting for it: the compiler turns a fetch-add on a uniform address into
 // its wave-aggregated form and reads the result back at once, which parks the calling wave (and,
-// at the next barrier, the workgroup) for the atomic's round trip once per item.  Here the ticket
-// stays in a register the compiler believes ready: the caller may only read it after a later
-// s_waitcnt vmcnt(0) of its own (the stage barrier's).  One lane calls this.
+// at the next barrier, the workgroup) for the atomic's round trip once per item.  Here the atomic
+// is issued by inline assembly, which the compiler's wait-count pass does not track: the register
+// it returns is NOT valid until the caller has passed it through queue_ticket_wait().  One lane
+// calls this.
 __device__ __forceinline__ int queue_take_async(WorkQueue* q, int h) {
     int ticket;
     const int one = 1;
     int* addr = &q->heads[h];
     asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(addr), "v"(one) : "memory");
+    return ticket;
+}
+// Makes the ticket of queue_take_async readable: waits for the wave's outstanding vector-memory
+// operations and ties the wait to the ticket's register, so that the compiler can neither read,
+// copy nor spill the register's final value before the wait.  Free right behind a barrier that
+// the wave entered with its copies landed.
+__device__ __forceinline__ int queue_ticket_wait(int ticket) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket));
     return ticket;
 }
 // called once per workgroup by one lane, after the value of its last queue_take has arrived
@@ -179,3 +190,24 @@ __device__ __forceinline__ void queue_leave(WorkQueue* q, int nheads, int nworkg
         __hip_atomic_store(&q->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
+// Host side of the slot pools: the slot a launch on `stream` may use, or -1 when it has to run
+// without a queue (items dealt statically, which every kernel supports): the stream is being
+// captured into a graph (a replay could run beside another user of the slot), or more than
+// SF_QUEUE_SLOTS different streams have launched this kernel family in this process.
+struct StreamSlots {
+    std::mutex mu;
+    hipStream_t streams[SF_QUEUE_SLOTS];
+    int n = 0;
+    int slot_of(hipStream_t s) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        if (st != hipStreamCaptureStatusNone) return -1;
+        std::lock_guard<std::mutex> lock(mu);
+        for (int i = 0; i < n; ++i)
+            if (streams[i] == s) return i;
+        if (n == SF_QUEUE_SLOTS) return -1;
+        streams[n] = s;
+        return n++;
+    }
+};

@@ -37,7 +37,7 @@ struct C3Params {
 __device__ __attribute__((aligned(16))) uint4 g_zero_chunk;  // never written: stays zero
 
 __device__ WorkQueue g_queues[SF_QUEUE_SLOTS];
-std::atomic<unsigned> g_launches{0};     // hands out the queue slots of this file's kernels, round-robin
+StreamSlots g_slots;     // which queue slot the launches of a stream use
 
 #ifdef SF_CONV3_STAMPS
 // diagnostic build only (tools/conv_stamps.py): shader-clock stamps of wave 0 of every workgroup
@@ -777,7 +777,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         advance(nxt);
     };
     auto park = [&]() {
-        if (dyn && tid == 0 && q_have) { s_next[q_par] = nb8 + q_pending; q_have = false; }
+        if (dyn && tid == 0 && q_have) { s_next[q_par] = nb8 + queue_ticket_wait(q_pending); q_have = false; }
     };
     while (true) {
         // the stage's copy has landed (own vmcnt, then the barrier) and every wave is done
@@ -805,7 +805,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     }
     if (p.qslot >= 0 && tid == 0) {
         // the last take has returned before the workgroup counts as gone
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q_pending) :: "memory");
         queue_leave(wq, 8, gridDim.x);
     }
 }
@@ -892,7 +892,7 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
     long long items = ntiles * p.ktiles;
     long long grid = (items + 7) / 8 * 8;
     if (grid > 256) grid = 256;
-    p.qslot = items > grid ? (int)(g_launches.fetch_add(1) % SF_QUEUE_SLOTS) : -1;    // one item each: nothing to deal
+    p.qslot = items > grid ? g_slots.slot_of(s) : -1;    // one item each: nothing to deal
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(D_NT), lds, s, p);
     SF_LAUNCH_CHECK("sf_conv3x3");
     return SF_OK;

@@ -37,7 +37,7 @@ static_assert(WJOBS % 8 == 0, "every wave copies the same number of weight piece
 __device__ __forceinline__ int swz(int row) { return (row >> 3) & 1; }
 
 __device__ WorkQueue g_queues[SF_QUEUE_SLOTS];
-std::atomic<unsigned> g_launches{0};     // hands out the queue slots of this file's kernels, round-robin
+StreamSlots g_slots;     // which queue slot the launches of a stream use
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -346,7 +346,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     };
     advance(nxt);
     auto park = [&]() {
-        if (dyn && tid == 0 && q_have) { s_next[q_par] = nb8 + q_pending; q_have = false; }
+        if (dyn && tid == 0 && q_have) { s_next[q_par] = nb8 + queue_ticket_wait(q_pending); q_have = false; }
     };
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
         const StageSrc ss = stage_src(nxt, nxt.q < nitems);
@@ -372,7 +372,7 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     }
     if (p.qslot >= 0 && tid == 0) {
         // the last take has returned before the workgroup counts as gone
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q_pending) :: "memory");
         queue_leave(wq, 8, gridDim.x);
     }
 }
@@ -497,7 +497,7 @@ extern "C" int sf_conv4x4s2(const void* in, const void* wp, const float* bias, c
     const long long items = ntiles * p.ktiles * (dgrad ? 4 : 1);
     long long grid = (items + 7) / 8 * 8;
     if (grid > 256) grid = 256;
-    p.qslot = items > grid ? (int)(g_launches.fetch_add(1) % SF_QUEUE_SLOTS) : -1;    // one item each: nothing to deal
+    p.qslot = items > grid ? g_slots.slot_of((hipStream_t)stream) : -1;    // one item each: nothing to deal
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(S_NT), lds, (hipStream_t)stream, p);
     SF_LAUNCH_CHECK("sf_conv4x4s2");
     return SF_OK;

@@ -453,11 +453,24 @@ std::mutex scratch_mutex;
 double* scratch_ptr[MAX_DEVICES];     // device address of `scratch` per device, null until first use
 
 // Device address of this device's copy of `scratch` (looked up once per device, with that device current).
-int static_scratch(double** out) {
+int static_scratch(hipStream_t stream, double** out) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
         sf_set_error("sf_image_station_loss_static: no current device, or device index above %d", MAX_DEVICES - 1);
         return SF_EINVAL;
+    }
+    // the kernels run on the stream's device: it has to be the current one, whose copy of the array is used
+    if (stream) {
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice(stream, &sdev) != hipSuccess) {
+            (void)hipGetLastError();
+            sf_set_error("sf_image_station_loss_static: not a valid stream");
+            return SF_EINVAL;
+        }
+        if ((int)sdev != dev) {
+            sf_set_error("sf_image_station_loss_static: the stream belongs to device %d but device %d is current", (int)sdev, dev);
+            return SF_EINVAL;
+        }
     }
     std::lock_guard<std::mutex> lock(scratch_mutex);
     if (!scratch_ptr[dev]) {
@@ -486,7 +499,7 @@ extern "C" int sf_image_station_loss_static(const float* pred, const float* targ
     SF_REQUIRE(S <= SF_LOSS_STATIC_MAX_STATIONS, "sf_image_station_loss_static: %d stations, the limit is %d", S,
                SF_LOSS_STATIC_MAX_STATIONS);
     double* ws = nullptr;
-    const int rc = static_scratch(&ws);
+    const int rc = static_scratch((hipStream_t)stream, &ws);
     if (rc != SF_OK) return rc;
     // every call writes all the partial-sum slots it later reads (nothing has to start at zero), so
     // the previous call's contents of the array are never seen

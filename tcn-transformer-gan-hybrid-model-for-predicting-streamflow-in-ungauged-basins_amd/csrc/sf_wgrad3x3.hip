@@ -57,7 +57,7 @@ struct StealQueue {
     int pad[3];
 };
 __device__ StealQueue g_wqueues[SF_QUEUE_SLOTS];    // zero between launches: the last workgroup to leave resets its slot
-std::atomic<unsigned> g_wlaunches{0};
+StreamSlots g_wslots;
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_tr_p;
 
@@ -681,9 +681,9 @@ int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t
     const int pairs = p.kt_tiles * p.ct_tiles;
     const bool queue_ok = g_dynamic_tiles.load() && (nslices & 7) == 0 && nslices <= 512 &&
                           nslices * pairs <= STEAL_WORKERS && (p.TH + 2) * (p.TW + 2) <= 368 && p.ntiles > nslices;
-    p.qslot = queue_ok ? (int)(g_wlaunches.fetch_add(1) % SF_QUEUE_SLOTS) : -1;
+    p.qslot = queue_ok ? g_wslots.slot_of(s) : -1;
     p.shirk = g_dynamic_tiles.load() == 2;
-    if (queue_ok) hipLaunchKernelGGL(wgrad3_dma_kernel<true>, dim3((unsigned)(nslices * pairs)), dim3(NTW), lds, s, p);
+    if (p.qslot >= 0) hipLaunchKernelGGL(wgrad3_dma_kernel<true>, dim3((unsigned)(nslices * pairs)), dim3(NTW), lds, s, p);
     else hipLaunchKernelGGL(wgrad3_dma_kernel<false>, dim3((unsigned)(nslices * pairs)), dim3(NTW), lds, s, p);
     const long long total = (long long)K * 9 * Cin;
     int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;

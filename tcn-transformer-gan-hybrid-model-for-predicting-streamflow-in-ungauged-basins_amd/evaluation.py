@@ -57,18 +57,27 @@ def calculate_psnr(pred: np.ndarray, target: np.ndarray, data_range: Optional[fl
 
 
 def calculate_metrics(predictions, targets) -> Dict[str, float]:
-    """RMSE, MAE, R2, NSE, MAPE (%), KGE of two equally shaped arrays / tensors
-    (src/loss.py:239-344 for inputs of equal shape; non-finite values count as zero)."""
+    """RMSE, MAE, R2, NSE, MAPE (%), KGE of predictions against targets (src/loss.py:239-344;
+    non-finite values count as zero).  A 4-D [B,C,h,w] or 3-D [C,h,w] target whose shape differs
+    from the prediction's is first resized bilinearly (align_corners=False) to the prediction's
+    last two dimensions, as src/loss.py:254-271 does with F.interpolate; here that resize is the
+    HIP kernel, so this one case needs the GPU.  Any other shape mismatch raises ValueError (the
+    reference fails in NumPy's broadcast at the same point)."""
     def flat(a):
         if isinstance(a, torch.Tensor):
             a = a.detach().cpu().numpy()
         return np.nan_to_num(np.asarray(a).reshape(-1), nan=0.0, posinf=0.0, neginf=0.0)
 
+    ps, ts = tuple(np.shape(predictions)), tuple(np.shape(targets))
+    if ps != ts and len(ts) in (3, 4) and len(ps) >= 2:
+        t4 = torch.as_tensor(np.asarray(targets) if not isinstance(targets, torch.Tensor) else targets).detach().float()
+        t4 = t4.reshape((-1, 1) + ts[-2:])                 # every (batch, channel) plane is resized on its own
+        targets = resize_bilinear(t4, int(ps[-2]), int(ps[-1]), "cuda").reshape(ts[:-2] + (int(ps[-2]), int(ps[-1])))
     p, t = flat(predictions), flat(targets)
     zero = {"RMSE": 0.0, "MAE": 0.0, "R2": 0.0, "NSE": 0.0, "MAPE": 0.0, "KGE": 0.0}
-    if p.shape != t.shape:
-        raise ValueError("calculate_metrics: shapes differ (resize the target first)")
-    if p.size == 0:
+    if p.size and t.size and p.shape != t.shape:
+        raise ValueError(f"calculate_metrics: {ps} against {ts} cannot be compared (only 3-D / 4-D targets are resized)")
+    if p.size == 0 or t.size == 0:
         return zero
     err = p - t
     ss_res, ss_tot = float((err ** 2).sum()), float(((t - t.mean()) ** 2).sum())

@@ -6,6 +6,7 @@ channel counts padded to a multiple of 8.
 """
 from __future__ import annotations
 
+import warnings
 from typing import List, Optional, Sequence
 
 import torch
@@ -23,11 +24,25 @@ def set_compute_dtype(dtype: Optional[torch.dtype]):
     _FORCED_DTYPE = dtype
 
 
+_WARNED_FP16 = False
+
+
 def compute_dtype() -> torch.dtype:
-    """bf16 inside torch.autocast('cuda') (the reference's AMP switch, src/train.py:192), else f32."""
+    """bf16 inside torch.autocast('cuda') (the reference's AMP switch, src/train.py:192), else f32.
+    The kernels have no fp16 form: an autocast region that asks for float16 (torch's default for
+    'cuda', which is what the reference's `amp.autocast(device_type='cuda')` gets) is computed in
+    bf16 with f32 accumulation, and says so once per process."""
+    global _WARNED_FP16
     if _FORCED_DTYPE is not None:
         return _FORCED_DTYPE
-    return torch.bfloat16 if torch.is_autocast_enabled("cuda") else torch.float32
+    if not torch.is_autocast_enabled("cuda"):
+        return torch.float32
+    if not _WARNED_FP16 and torch.get_autocast_dtype("cuda") == torch.float16:
+        _WARNED_FP16 = True
+        warnings.warn("torch.autocast('cuda') asks for float16; the HIP kernels compute in bfloat16 with float32 "
+                      "accumulation instead (no loss scaling is needed; a GradScaler around them stays at its scale)",
+                      UserWarning, stacklevel=2)
+    return torch.bfloat16
 
 
 def new_seed() -> int:

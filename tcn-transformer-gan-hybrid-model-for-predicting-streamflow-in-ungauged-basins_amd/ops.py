@@ -571,7 +571,9 @@ def derived(owner: torch.Tensor, key, build):
 
 
 def _shadow_key(p: torch.Tensor):
-    return (p._version, p.data_ptr(), tuple(p.shape))
+    # the same staleness rules as derived(): writes through torch, writes announced by touch() /
+    # bump_weight_epoch(), a move to another address
+    return (WEIGHT_EPOCH, p.__dict__.get("_sf_epoch", 0), p._version, p.data_ptr(), tuple(p.shape))
 
 
 def shadow_if_current(p: torch.Tensor) -> Optional[torch.Tensor]:
@@ -590,6 +592,8 @@ def weight_shadow(p: torch.Tensor) -> torch.Tensor:
 
 
 def mark_shadow_current(p: torch.Tensor):
+    """The shadow was just rewritten together with the parameter (sf_adam_guarded): call this AFTER
+    the touch() that announces the parameter write, so that the key holds the new epoch."""
     p._sf_shadow_key = _shadow_key(p)
 
 

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import logging
 import os
+import time
 from datetime import datetime
 from pathlib import Path
 from typing import Dict, Iterable, List, Optional, Tuple
@@ -130,6 +131,7 @@ class FlatAdam:
             ops.adam_guarded(self.flat[a:e], self.gsmall[a:e], self.m[a:e], self.v[a:e], self.lr, b1, b2, self.eps,
                              self.state, found_inf, grad_scale, step_offset=off)
         ns = len(self.small)
+        shadowed = []
         for i, (p, (fl, m, v)) in enumerate(zip(self.big, self._big_views)):
             if p.grad is None:
                 continue
@@ -137,7 +139,7 @@ class FlatAdam:
             ops.adam_guarded(fl, p.grad.contiguous().view(-1), m, v, self.lr, b1, b2, self.eps, self.state, found_inf,
                              grad_scale, shadow=shadow, step_offset=self._seen[ns + i] - self._calls)
             if shadow is not None:
-                ops.mark_shadow_current(p)
+                shadowed.append(p)
         self._calls += 1
         for i, p in enumerate(self.params):
             if p.grad is not None:
@@ -145,6 +147,8 @@ class FlatAdam:
             else:
                 self._uniform = False
         ops.touch(p for p in self.params if p.grad is not None)   # only this network's packed weights go stale
+        for p in shadowed:                  # written by the same kernel as the parameter: current again
+            ops.mark_shadow_current(p)
 
     def grads(self) -> List[torch.Tensor]:
         """The tensors an Inf/NaN check of this step's gradients has to look at (after gather())."""
@@ -227,8 +231,12 @@ class Trainer:
         self.nan_flags = torch.zeros(4, device=self.device, dtype=torch.int32)
         self._one = torch.ones(1, device=self.device)      # the 'real' label of the adversarial losses
         self.found_inf = torch.zeros(2, device=self.device, dtype=torch.int32)    # generator / discriminator gradients
+        self._skips_reported = (0, 0)      # skipped generator / discriminator steps already told by nan_report
         self._pending: List = []
         self._reduce_now = False
+        self.comm_events: Optional[List] = None     # when a list: (before, after) event pairs around the waits
+        self.comm_host_s = 0.0
+        self._device_collectives = False
         if self.distributed:
             # RCCL works on device tensors and is ordered against streams; any other backend (gloo on
             # hosts without a device transport) gets the gradients staged through host memory
@@ -283,9 +291,12 @@ class Trainer:
             # keeps `t` alive until its own stream is done, and _wait_reduces orders every later use)
             self._pending.append(work)
         else:
+            t0 = time.perf_counter() if self.comm_events is not None else 0.0
             host = t.detach().to("cpu")
             dist.all_reduce(host)
             t.copy_(host, non_blocking=False)
+            if self.comm_events is not None:       # staged: the whole exchange is exposed, and the host pays it
+                self.comm_host_s += time.perf_counter() - t0
 
     def _install_early_reduce(self):
         """The two 262144-wide Linear weights are 95 % of the gradient bytes; their gradients are
@@ -300,9 +311,31 @@ class Trainer:
             p.register_post_accumulate_grad_hook(hook)
 
     def _wait_reduces(self):
+        """The compute stream waits for the collectives issued so far (the host does not).  With
+        `comm_events` set to a list, an event pair brackets the wait on the compute stream: the
+        time between the two is what the exchange costs the step beyond what the backward hid
+        (the stream was idle, waiting for the communication stream)."""
+        if not self._pending:
+            return
+        timed = self.comm_events is not None and self._device_collectives
+        if timed:
+            before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            before.record()
         for w in self._pending:
-            w.wait()            # the current (compute) stream waits for the collective's stream; the host does not
+            w.wait()
+        if timed:
+            after.record()
+            self.comm_events.append((before, after))
         self._pending = []
+
+    def comm_exposed_ms(self) -> float:
+        """Milliseconds the steps so far spent waiting for gradient exchange that the backward did
+        not hide, since `comm_events` was last set to an empty list (host-synchronising).  RCCL:
+        from the event pairs of _wait_reduces; staged transports: the host time of the exchange."""
+        if self.comm_events is None:
+            return 0.0
+        torch.cuda.synchronize(self.device)
+        return sum(a.elapsed_time(b) for a, b in self.comm_events) + self.comm_host_s * 1e3
 
     def _d_grads_consumed(self, bi: int) -> bool:
         """Discriminator gradients produced in batch `bi` are used by an optimiser step only if
@@ -537,13 +570,18 @@ class Trainer:
     def nan_report(self) -> Dict:
         """Host-synchronising read (and reset) of the device flags: 'flags' = [input images,
         predictions, loss, gradients] saw Inf/NaN since the last report (src/train.py:193,198,221;
-        the fourth is what GradScaler checks), 'skipped_steps' = optimiser steps skipped so far."""
+        the fourth is what GradScaler checks: an optimiser step of either network was skipped
+        since the last report), 'skipped_steps' = generator steps skipped so far,
+        'skipped_steps_d' = discriminator steps skipped so far (both cumulative)."""
         vals = self.nan_flags.tolist()
         self.nan_flags.zero_()
-        skipped = self.opt_g.skipped
-        if skipped:
+        skipped_g = self.opt_g.skipped
+        skipped_d = self.opt_d.skipped if self.use_gan else 0
+        seen_g, seen_d = self._skips_reported
+        if skipped_g > seen_g or skipped_d > seen_d:
             vals[_FLAG_GRADS] = 1
-        return {"flags": [bool(v) for v in vals], "skipped_steps": skipped}
+        self._skips_reported = (skipped_g, skipped_d)
+        return {"flags": [bool(v) for v in vals], "skipped_steps": skipped_g, "skipped_steps_d": skipped_d}
 
     def saw_nan_or_inf(self) -> bool:
         """True when any of the checks fired since the last read (host-synchronising)."""

@@ -67,6 +67,29 @@ def checksum(sd: Dict[str, torch.Tensor], keys: Iterable[str] = None) -> Dict[st
     return out
 
 
+def update_projection(after: Dict[str, torch.Tensor], before: Dict[str, torch.Tensor], keys: Iterable[str]
+                      ) -> Dict[str, np.ndarray]:
+    """Per key [sum_k r_k * (after - before)_k, ||after - before||_2] in float64, r a fixed
+    pseudo-random +-1 / normal direction made from the key's name.  Unlike an abs-sum checksum of
+    the parameter itself, a signed projection of the UPDATE moves by the full size of any error in
+    it: a missing, doubled or mis-signed optimiser step on a tensor changes it by O(1) of itself."""
+    out = {}
+    for k in keys:
+        d = (after[k].detach().to(torch.float64) - before[k].detach().to(torch.float64)).cpu().numpy()
+        r = gold_array("proj/" + k, d.shape, 1.0, np.float64)
+        out[k] = np.array([float((r * d).sum()), float(np.sqrt((d * d).sum()))])
+    return out
+
+
+def update_signs(after: Dict[str, torch.Tensor], before: Dict[str, torch.Tensor], keys: Iterable[str]) -> np.ndarray:
+    """[after > before] of every entry of the given tensors, concatenated in key order and packed
+    eight to a byte.  Adam's FIRST step moves every entry by exactly lr against the sign of its
+    gradient, so for a network that has taken one step these bits are the whole update."""
+    bits = [(after[k].detach().to(torch.float64) > before[k].detach().to(torch.float64)).cpu().numpy().reshape(-1)
+            for k in keys]
+    return np.packbits(np.concatenate(bits))
+
+
 # ---- pixel-map sweep: random points, exact .5 ties, edges, outside-region points
 PIXEL_CASES = [
     ((100.0, 110.0, 25.0, 35.0), 128, 128),

@@ -291,6 +291,25 @@ def gen_losses():
     save("losses", **out)
 
 
+def gen_metrics_resize():
+    """calculate_metrics with a target of another shape (src/loss.py:254-271): 4-D and 3-D targets
+    are resized bilinearly to the prediction's last two dimensions first."""
+    keys = ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE")
+    out = {}
+    p4 = G.gold_tensor("mres/p4", (3, 2, 40, 48)) + 2.0
+    t4 = G.gold_tensor("mres/t4", (3, 2, 20, 24)) + 2.0
+    m = calculate_metrics(p4, t4)
+    out["m4"] = np.array([m[k] for k in keys])
+    p3 = G.gold_tensor("mres/p3", (2, 30, 50)) + 1.5
+    t3 = G.gold_tensor("mres/t3", (2, 12, 20)) + 1.5
+    m = calculate_metrics(p3, t3)
+    out["m3"] = np.array([m[k] for k in keys])
+    t4d = G.gold_tensor("mres/t4d", (3, 2, 100, 96)) + 2.0          # a larger target: resized DOWN
+    m = calculate_metrics(p4, t4d)
+    out["m4_down"] = np.array([m[k] for k in keys])
+    save("metrics_resize", **out)
+
+
 # ------------------------------------------------------------------ 7. full generator forward
 def model_cfg(hidden, temporal, size, channels, use_gan=False, accum=1, k=3):
     return {
@@ -360,6 +379,8 @@ def gen_train():
             load_gold(tr.discriminator, "trn_d_" + tag)
         batches = make_batches(4, 2, 3, 64)
         losses = []
+        g_init = {k: v.clone() for k, v in tr.model.state_dict().items()}
+        d_init = {k: v.clone() for k, v in tr.discriminator.state_dict().items()} if use_gan else None
 
         class Rec(list):
             pass
@@ -386,6 +407,8 @@ def gen_train():
         cs = G.checksum(gsd, [k for k in gsd if "num_batches" not in k and "pos_encoder" not in k])
         out[f"{tag}_gkeys"] = np.array(list(cs.keys()))
         out[f"{tag}_gsum"] = np.stack(list(cs.values()))
+        pj = G.update_projection(gsd, g_init, list(cs.keys()))
+        out[f"{tag}_gproj"] = np.stack([pj[k] for k in cs])
         out[f"{tag}_g_dec_out_w"] = gsd["decoder.output_conv.weight"]
         out[f"{tag}_g_bn1_rm"] = gsd["cnn_encoder.encoder.1.running_mean"]
         if use_gan:
@@ -393,6 +416,9 @@ def gen_train():
             cs = G.checksum(dsd, [k for k in dsd if "num_batches" not in k])
             out[f"{tag}_dkeys"] = np.array(list(cs.keys()))
             out[f"{tag}_dsum"] = np.stack(list(cs.values()))
+            pj = G.update_projection(dsd, d_init, list(cs.keys()))
+            out[f"{tag}_dproj"] = np.stack([pj[k] for k in cs])
+            out[f"{tag}_dsign"] = G.update_signs(dsd, d_init, list(cs.keys()))      # D takes one step in 4 batches
             out[f"{tag}_d_m5_b"] = dsd["model.5.bias"]
             out[f"{tag}_d_bn2_rv"] = dsd["model.2.1.running_var"]
     save("train", **out)
@@ -619,10 +645,12 @@ def gen_baselines():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pixel", "encoder", "temporal", "decoder", "disc", "losses", "generator",
-                             "train", "evaluate", "dataset", "ckpt", "baselines", "evaluate_csv", "disc_eval", "options"]
+                             "train", "evaluate", "dataset", "ckpt", "baselines", "evaluate_csv", "disc_eval", "options",
+                             "metrics_resize"]
     fns = {"pixel": gen_pixel, "encoder": gen_encoder, "temporal": gen_temporal, "decoder": gen_decoder,
            "disc": gen_disc, "losses": gen_losses, "generator": gen_generator, "train": gen_train,
            "evaluate": gen_evaluate, "dataset": gen_dataset, "ckpt": gen_ckpt, "baselines": gen_baselines,
-           "evaluate_csv": gen_evaluate_csv, "disc_eval": gen_disc_eval, "options": gen_options}
+           "evaluate_csv": gen_evaluate_csv, "disc_eval": gen_disc_eval, "options": gen_options,
+           "metrics_resize": gen_metrics_resize}
     for w in which:
         fns[w]()

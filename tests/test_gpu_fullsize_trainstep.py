@@ -3,8 +3,9 @@
 src/train.py:154-305) in f32 mode, two samples per batch, three batches (a discriminator batch and
 two generator-only batches of the reference's schedule): loss trajectory against the CPU oracle's
 TrainerOracle on the same weights and inputs (5e-4, the tolerance of the golden trajectory test),
-and abs-sum checksums of every generator / discriminator tensor after the three fused Adam steps
-(1e-3)."""
+abs-sum checksums of every generator / discriminator tensor after the three fused Adam steps
+(1e-3), and the parameter UPDATES themselves, tensor by tensor: norm and direction (cosine) of
+(after - before) against the oracle's."""
 import importlib
 
 import numpy as np
@@ -12,7 +13,7 @@ import pytest
 import torch
 
 import goldgen as G
-from conftest import load_pkg
+from conftest import NOISE_DRIVEN, PARTLY_NOISE_DRIVEN, load_pkg
 from oracle import streamflow_oracle as O
 from test_gpu_parity import load_gold
 
@@ -55,6 +56,7 @@ def test_full_size_train_steps_against_oracle(mode):
     d_sd = load_gold(tr.discriminator, "fs_d")
     tr.model.temporal_module.dropout = 0.0
     ref = O.TrainerOracle(CFG, {k: v.clone() for k, v in g_sd.items()}, {k: v.clone() for k, v in d_sd.items()})
+    init = {id(tr.model): {k: v.clone() for k, v in g_sd.items()}, id(tr.discriminator): {k: v.clone() for k, v in d_sd.items()}}
     keys = ("total", "image", "station", "gan_g", "gan_d")
     for i, b in enumerate(_batches(3)):
         args = (b["images"], b["output_image"], b["station_positions"], b["stations"])
@@ -75,3 +77,26 @@ def test_full_size_train_steps_against_oracle(mode):
                 continue
             a, b_ = float(v.double().abs().sum()), float(sd[k].detach().double().abs().sum())
             assert abs(a - b_) <= 1e-3 * max(b_, 1e-6), (k, a, b_)
+    # The updates: three Adam steps of the generator, one of the discriminator.  Adam normalises
+    # every entry's step to about lr, so an entry whose gradient is within rounding of zero moves
+    # in the direction of the rounding noise: two correct f32 implementations differ in the sign of
+    # a fraction f of the entries and reach cos = 1 - 2 f, not 1.  Bounds: f32 cos >= 0.99 and
+    # norms to 5e-3; bf16 (a precision statement, the oracle stays f32) cos >= 0.8, norms to 10 %.
+    cos_min, norm_tol = (0.99, 5e-3) if mode == "f32" else (0.8, 0.1)
+    bad, worst = [], (2.0, "")
+    for mod, sd in ((tr.model, ref.g_sd), (tr.discriminator, ref.d_sd)):
+        for k, v in mod.state_dict().items():
+            if not v.dtype.is_floating_point or "running" in k or k.endswith("pos_encoder.pe") or k in NOISE_DRIVEN:
+                continue
+            w0 = init[id(mod)][k].double()
+            da, db = v.detach().cpu().double() - w0, sd[k].detach().double() - w0
+            na, nb = float(da.norm()), float(db.norm())
+            assert nb > 0.0, k
+            cos = float((da * db).sum()) / max(na * nb, 1e-300)
+            need = 0.6 if k.endswith(PARTLY_NOISE_DRIVEN) else cos_min
+            if cos < worst[0]:
+                worst = (cos, k)
+            if cos < need or abs(na - nb) > norm_tol * nb:
+                bad.append(f"{k}: cos {cos:.5f} (need {need}), |update| {na:.4e} against {nb:.4e}")
+    print(f"[{mode}] least aligned update: {worst[1]} cos {worst[0]:.5f}")
+    assert not bad, "\n".join(bad)

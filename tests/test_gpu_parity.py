@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import goldgen as G
-from conftest import close, close_elementwise, close_robust, golden, load_pkg
+from conftest import check_update_projection, check_update_signs, close, close_elementwise, close_robust, golden, load_pkg
 from oracle import streamflow_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -384,6 +384,8 @@ def test_train_epoch_semantics_f32(sf, temporal, use_gan, accum, tag):
     tr.model.temporal_module.dropout = 0.0
     if use_gan:
         load_gold(tr.discriminator, "trn_d_" + tag)
+    g_init = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    d_init = {k: v.detach().cpu().clone() for k, v in tr.discriminator.state_dict().items()} if use_gan else None
     rows = []
     for b in make_batches(4, 2, 3, 64):
         o = tr.train_step(b["images"], b["output_image"], b["station_positions"], b["stations"])
@@ -400,11 +402,17 @@ def test_train_epoch_semantics_f32(sf, temporal, use_gan, accum, tag):
     keys = [str(k) for k in g[f"{tag}_gkeys"]]
     cs = G.checksum(gsd, keys)
     np.testing.assert_allclose(np.stack([cs[k] for k in keys])[:, 1], g[f"{tag}_gsum"][:, 1], rtol=5e-4)
+    # the updates themselves: signed projection and norm of (after - before) per tensor
+    check_update_projection(gsd, g_init, keys, g[f"{tag}_gproj"])
     close(gsd["decoder.output_conv.weight"], g[f"{tag}_g_dec_out_w"], 2e-3)
     close(gsd["cnn_encoder.encoder.1.running_mean"], g[f"{tag}_g_bn1_rm"], 1e-4)
     if use_gan:
         dsd = {k: v.cpu() for k, v in tr.discriminator.state_dict().items()}
         keys = [str(k) for k in g[f"{tag}_dkeys"]]
+        # the discriminator takes exactly one Adam step in these four batches (the schedule quirk):
+        # every entry moves by lr against the sign of its gradient
+        check_update_projection(dsd, d_init, keys, g[f"{tag}_dproj"], tol_proj=0.3)
+        check_update_signs(dsd, d_init, keys, g[f"{tag}_dsign"])
         cs = G.checksum(dsd, keys)
         np.testing.assert_allclose(np.stack([cs[k] for k in keys])[:, 1], g[f"{tag}_dsum"][:, 1], rtol=5e-4)
         close(dsd["model.5.bias"], g[f"{tag}_d_m5_b"], 2e-3)
@@ -941,3 +949,22 @@ def test_token_outer4_against_matmul(sf):
     (O.transformer_forward(x.cpu(), sd, prefix="", num_layers=2, nhead=4) * u.cpu()).sum().backward()
     for k, p in m.named_parameters():
         close(p.grad, sd[k].grad.numpy(), 2e-4)
+
+
+def test_calculate_metrics_resizes_targets(sf):
+    """calculate_metrics with a 4-D / 3-D target of another shape (src/loss.py:254-271): the target is
+    resized bilinearly (align_corners=False, here by sf_bilinear_fwd) to the prediction's grid first.
+    Golden: the reference's own numbers, for targets smaller and larger than the prediction."""
+    g = golden("metrics_resize")
+    keys = ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE")
+    p4 = G.gold_tensor("mres/p4", (3, 2, 40, 48)) + 2.0
+    p3 = G.gold_tensor("mres/p3", (2, 30, 50)) + 1.5
+    for tag, p, t in (("m4", p4, G.gold_tensor("mres/t4", (3, 2, 20, 24)) + 2.0),
+                      ("m3", p3, G.gold_tensor("mres/t3", (2, 12, 20)) + 1.5),
+                      ("m4_down", p4, G.gold_tensor("mres/t4d", (3, 2, 100, 96)) + 2.0)):
+        m = sf.calculate_metrics(p.to(DEV), t)                     # device prediction, host target
+        np.testing.assert_allclose([m[k] for k in keys], g[tag], rtol=1e-5, atol=1e-7)
+        m = sf.calculate_metrics(p.numpy(), t.numpy())             # arrays work as tensors do
+        np.testing.assert_allclose([m[k] for k in keys], g[tag], rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):                                # 2-D: not resized; sizes differ (NumPy's broadcast error in the reference)
+        sf.calculate_metrics(torch.zeros(4, 5), torch.zeros(3, 5))

@@ -113,8 +113,14 @@ def test_nan_checks_warn_and_the_step_is_skipped(sf, training, caplog):
     assert torch.equal(tr.opt_g.flat, g0) and torch.equal(tr.opt_d.flat, d0)
     assert float(tr.opt_g.m.abs().sum()) == 0.0 and float(tr.opt_g.v.abs().sum()) == 0.0
     assert (tr.opt_g.t, tr.opt_g.skipped, tr.opt_d.t, tr.opt_d.skipped) == (0, 1, 0, 1)
+    # train_epoch's own read at the end of the epoch has already reported the skip: the flag says
+    # "since the last report", the counters are cumulative
     rep = tr.nan_report()
-    assert rep["skipped_steps"] == 1 and rep["flags"][3]
+    assert rep["skipped_steps"] == 1 and rep["skipped_steps_d"] == 1 and not any(rep["flags"])
+    tr.train_step(bad["images"], bad["output_image"], bad["station_positions"], bad["stations"])
+    rep = tr.nan_report()
+    assert rep["flags"] == [True, True, True, True] and rep["skipped_steps"] == 2
+    assert not tr.saw_nan_or_inf()          # nothing new since
     caplog.clear()
     with caplog.at_level(logging.WARNING, logger="Trainer"):
         res = tr.train_epoch([batches[1]])

@@ -65,3 +65,49 @@ def test_cached_weights_follow_the_parameter(sf, which):
     assert torch.equal(y2, fresh(state()))
     m.load_state_dict(s0)                                 # load_state_dict copies in place
     assert torch.equal(out(), fresh(s0))
+
+
+def test_linear_weight_shadow_follows_the_parameter(sf):
+    """The bf16 shadow of a big Linear weight (written by FlatAdam's kernel beside the f32 master)
+    must go stale like every other derived copy: after a write through `.data` announced by
+    ops.bump_weight_epoch(), and after ops.touch() by an optimiser that does not maintain it."""
+    import importlib
+    training = importlib.import_module(sf.__name__ + ".training")
+    F = importlib.import_module(sf.__name__ + ".functional")
+    ops = sf.ops
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(4096, 64).to(DEV)
+    x = torch.randn(8, 4096, device=DEV)
+
+    def out():
+        with torch.no_grad():
+            return F.linear(x, lin, torch.bfloat16).float()
+
+    def fresh():
+        w16 = lin.weight.detach().to(torch.bfloat16).float()
+        return (x.to(torch.bfloat16).float() @ w16.t() + lin.bias.detach()).float()
+
+    def check():
+        y, want = out(), fresh()
+        assert float((y - want).abs().max()) <= 2e-3 * float(want.abs().max())
+
+    opt = training.FlatAdam(lin, 1e-2, big_numel=1 << 16, shadow_big=True)
+    assert [tuple(p.shape) for p in opt.big] == [(64, 4096)]
+    for _ in range(2):                                    # the kernel writes parameter and shadow together
+        lin.weight.grad = torch.randn_like(lin.weight)
+        lin.bias.grad = torch.randn_like(lin.bias)
+        opt.gather()
+        opt.step()
+        opt.zero_grad()
+        assert ops.shadow_if_current(lin.weight) is not None
+        check()
+    lin.weight.data.mul_(-2.0)                            # torch does not count this write
+    ops.bump_weight_epoch()
+    assert ops.shadow_if_current(lin.weight) is None
+    check()
+    sh = ops.weight_shadow(lin.weight)                    # rebuilt by a cast: current again
+    assert ops.shadow_if_current(lin.weight) is sh
+    lin.weight.data.mul_(0.25)                            # an optimiser kernel without a shadow of its own
+    ops.touch([lin.weight])
+    assert ops.shadow_if_current(lin.weight) is None
+    check()

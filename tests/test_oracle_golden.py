@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import goldgen as G
-from conftest import golden, close, close_robust
+from conftest import golden, close, close_robust, check_update_projection, check_update_signs
 from oracle import streamflow_oracle as O
 
 torch.set_num_threads(8)
@@ -327,6 +327,8 @@ def test_train_epoch_semantics(temporal, use_gan, accum, tag):
     gsd = gstate(generator_shapes(3, 16, temporal), "trn_g_" + tag)
     dsd = gstate(disc_shapes(64), "trn_d_" + tag) if use_gan else None
     tr = O.TrainerOracle(cfg, gsd, dsd)
+    g_init = {k: v.detach().clone() for k, v in tr.g_sd.items()}
+    d_init = {k: v.detach().clone() for k, v in tr.d_sd.items()} if use_gan else None
     rows = []
     for b in make_batches(4, 2, 3, 64):
         o = tr.step(b["images"], b["output_image"], b["station_positions"], b["stations"])
@@ -339,9 +341,15 @@ def test_train_epoch_semantics(temporal, use_gan, accum, tag):
     cs = G.checksum(tr.g_sd, keys)
     got = np.stack([cs[k] for k in keys])
     np.testing.assert_allclose(got[:, 1], g[f"{tag}_gsum"][:, 1], rtol=2e-4)
+    check_update_projection(tr.g_sd, g_init, keys, g[f"{tag}_gproj"])
     close(tr.g_sd["decoder.output_conv.weight"], g[f"{tag}_g_dec_out_w"], 1e-3)
     close(tr.g_sd["cnn_encoder.encoder.1.running_mean"], g[f"{tag}_g_bn1_rm"], 1e-4)
     if use_gan:
+        dkeys = [str(k) for k in g[f"{tag}_dkeys"]]
+        # one Adam step in these four batches: every entry moved by lr, so the norms are exact, the
+        # signs are the update, and the projection sums 2 lr r_k over the few noise-level entries
+        check_update_projection(tr.d_sd, d_init, dkeys, g[f"{tag}_dproj"], tol_proj=0.3)
+        check_update_signs(tr.d_sd, d_init, dkeys, g[f"{tag}_dsign"])
         keys = [str(k) for k in g[f"{tag}_dkeys"]]
         cs = G.checksum(tr.d_sd, keys)
         got = np.stack([cs[k] for k in keys])
@@ -519,3 +527,16 @@ def test_discriminator_three_input_channels():
     for key in sd:
         if sd[key].requires_grad and key not in ("model.2.0.bias", "model.3.0.bias", "model.4.0.bias"):
             close(sd[key].grad, g[f"disc3_g_{key}"], 1e-3)
+
+
+def test_calculate_metrics_resizes_targets():
+    """src/loss.py:254-271: 4-D / 3-D targets of another shape are resized bilinearly first."""
+    g = golden("metrics_resize")
+    keys = ("RMSE", "MAE", "R2", "NSE", "MAPE", "KGE")
+    p4 = G.gold_tensor("mres/p4", (3, 2, 40, 48)) + 2.0
+    p3 = G.gold_tensor("mres/p3", (2, 30, 50)) + 1.5
+    for tag, p, t in (("m4", p4, G.gold_tensor("mres/t4", (3, 2, 20, 24)) + 2.0),
+                      ("m3", p3, G.gold_tensor("mres/t3", (2, 12, 20)) + 1.5),
+                      ("m4_down", p4, G.gold_tensor("mres/t4d", (3, 2, 100, 96)) + 2.0)):
+        m = O.calculate_metrics(p.numpy(), t.numpy())
+        np.testing.assert_allclose([m[k] for k in keys], g[tag], rtol=1e-5, atol=1e-7)
