@@ -384,17 +384,46 @@ int sf_lonlat_to_pixel(const double* lon, const double* lat, int n, double lon_m
                        double lat_min, double lat_max, int W, int H, int* px, int* py,
                        void* stream);
 /*
- * Fused ImageLoss + StationLoss forward AND backward (src/loss.py:47-70, 116-160, 227-230).
+ * ImageLoss + StationLoss + their weighted sum (src/loss.py:47-70, 116-160, 227-230).
  * pred f32 [B,1,H,W]; target f32 [B,1,TH,TW] (bilinearly resized to HxW on the fly when the
  * sizes differ); stations packed: pos int32 [S][2] (x=column, y=row), runoff f32 [S],
  * sample offsets int32 [B+1].  metric 0 = MSE, 1 = MAE (image_metric / station_metric).
- * losses f32 [4]: total, image, station, and 1 / (sum of the image loss's pixel weights).
- * dpred f32 [B,1,H,W]: d total / d pred = dpred * losses[3].  The weight sum is only complete
- * when the single pass over pred has finished, so the division is left to the caller, who
- * multiplies by the upstream gradient anyway (one scalar product, then one pass).
- * ws: SF_LOSS_WS_DOUBLES doubles of device scratch (per-block partial sums; no zeroing needed).
+ *
+ * sf_image_station_loss_fwd -- one launch, one read of pred and target.
+ *   losses f32 [5]: total, image, station, 1 / (sum of the image loss's pixel weights),
+ *     1 / (number of stations with a non-empty window) or 0 when there is none.
+ *   station_diff f32 [S], nullable: window mean - runoff of every station (0 for an empty window),
+ *     kept for the backward pass.
+ *   nan_flag int32 [1], nullable: |= 1 when pred holds Inf / NaN (the prediction check of the
+ *     training loop, src/train.py:198, which then needs no pass of its own); never cleared here.
+ *   ws: SF_LOSS_WS_DOUBLES doubles of device scratch: per-block partial sums (folded in a fixed
+ *     order by the block that finishes last: bit-reproducible losses) and in the last double an
+ *     arrival counter that MUST BE ZERO before the first call using this workspace; every call
+ *     leaves it zero.  Calls sharing a workspace must be ordered on one stream.
+ * sf_image_station_loss_bwd -- one launch, one read of pred and target, one write of dpred.
+ *   dpred f32 [B,1,H,W] = upstream * d total / d pred, complete (image term and the station
+ *     windows' terms summed in registers before the one store: no atomics, bit-reproducible).
+ *   upstream: device f32 [1], the gradient arriving at the total loss; NULL = 1.
+ *   station_diff: what the forward call wrote, or NULL (the window means are gathered again).
+ *   fwd_losses: the losses [5] the forward call on the same inputs wrote.
+ * sf_image_station_loss -- both, back to back, upstream 1: losses f32 [4] = total, image,
+ *   station, 1 (dpred is already divided by the weight sum; callers that multiply dpred by
+ *   losses[3] stay correct).  Its ws may hold anything (the counter is cleared on the stream).
  */
 #define SF_LOSS_WS_DOUBLES 4096
+int sf_image_station_loss_fwd(const float* pred, const float* target, const int* pos,
+                              const float* runoff, const int* offsets, int S, int B, int H, int W,
+                              int TH, int TW, int image_metric, float nonzero_weight,
+                              float zero_threshold, int ksize, int station_metric,
+                              float image_weight, float station_weight, float* losses,
+                              float* station_diff, int* nan_flag, double* ws, void* stream);
+int sf_image_station_loss_bwd(const float* pred, const float* target, const int* pos,
+                              const float* runoff, const int* offsets, int S, int B, int H, int W,
+                              int TH, int TW, int image_metric, float nonzero_weight,
+                              float zero_threshold, int ksize, int station_metric,
+                              float image_weight, float station_weight, const float* upstream,
+                              const float* station_diff, const float* fwd_losses, float* dpred,
+                              void* stream);
 int sf_image_station_loss(const float* pred, const float* target, const int* pos,
                           const float* runoff, const int* offsets, int S, int B, int H, int W,
                           int TH, int TW, int image_metric, float nonzero_weight,
@@ -410,8 +439,10 @@ int sf_image_station_loss(const float* pred, const float* target, const int* pos
  * nothing.  Limits (SF_EINVAL beyond them): B*H*W <= SF_LOSS_STATIC_MAX_PIXELS and
  * S <= SF_LOSS_STATIC_MAX_STATIONS.  All calls on one GPU share that GPU's array: calls that
  * overlap on one GPU (different streams or host threads) race; calls ordered on one stream do not
- * (every call rewrites all the slots it reads).  Make the first call on a device outside graph
- * capture.  Results are those of sf_image_station_loss.
+ * (every call rewrites all the slots it reads, and the arrival counter, zero when the library is
+ * loaded, is put back to zero by the call itself).  `stream` must belong to the current device.
+ * Make the first call on a device outside graph capture.  Results are those of
+ * sf_image_station_loss.
  */
 #define SF_LOSS_STATIC_MAX_PIXELS (1LL << 28)
 #define SF_LOSS_STATIC_MAX_STATIONS (1 << 20)

@@ -65,31 +65,35 @@ __device__ __forceinline__ int sample_of(const int* offsets, int B, int s) {
     return lo;
 }
 
-// Workspace layout (doubles): per-block partial sums, written in full by every call (nothing to
-// zero) and folded in a fixed order, so the losses are bit-reproducible.
-constexpr int LP = 1024;                  // max pixel blocks
-constexpr int LS = 1024;                  // max station blocks
+// Workspace layout (doubles): per-block partial sums, written in full by every call and folded in
+// a fixed order by whichever block finishes last, so the losses are bit-reproducible; the folded
+// scalars the backward pass needs; the arrival counter (zero between calls).
+constexpr int LP = 1020;                  // max pixel blocks
+constexpr int LS = 1020;                  // max station blocks
 constexpr int WS_W = 0;                   // [LP] sum of pixel weights
 constexpr int WS_L = LP;                  // [LP] sum of weight * pixel loss
 constexpr int WS_ST = 2 * LP;             // [LS] station loss terms
 constexpr int WS_SC = 2 * LP + LS;        // [LS] stations with a non-empty window
-static_assert(2 * LP + 2 * LS <= SF_LOSS_WS_DOUBLES, "loss workspace layout");
+constexpr int WS_SCAL = 2 * LP + 2 * LS;  // two floats: 1 / sum of pixel weights, 1 / stations counted (forward + backward in one call)
+constexpr int WS_ARRIVED = SF_LOSS_WS_DOUBLES - 1;   // int: blocks that have written their partials
+static_assert(WS_SCAL < WS_ARRIVED, "loss workspace layout");
 
 __device__ __forceinline__ float pixel_weight(const LossArgs& a, float t) {
     return 1.0f + (a.nonzero_weight - 1.0f) * (fabsf(t) > a.zero_threshold ? 1.0f : 0.0f);
 }
 
-// sum of n partials (n <= 1024) by one 256-thread block, fixed order; valid in every thread
-__device__ __forceinline__ double fold_partials(const double* __restrict__ part, int n, double* sm) {
+// sum of n partials (n <= 1024) by one 256-thread block, fixed order; valid in every thread.  The
+// partials were written by other workgroups of the same launch: they are read at agent scope.
+__device__ __forceinline__ double fold_partials(const double* part, int n, double* sm) {
     double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += NT) v += part[i];
+    for (int i = threadIdx.x; i < n; i += NT) v += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return block_sum_256_d(v, sm);
 }
 
-// The pixel passes walk the prediction grid by rows: a wave takes rows (b, y) = wave, wave + nwaves,
-// ... and its lanes take V consecutive pixels each, so the horizontal resize taps of a lane are
-// computed once and kept for all its rows, the vertical taps once per row, and all index
-// arithmetic is 32-bit.
+// The pixel passes walk the prediction grid by rows: a wave takes pairs of adjacent rows (b, y),
+// pair = wave, wave + nwaves, ... and its lanes take V consecutive pixels each of up to two column
+// groups, so the horizontal resize taps of a lane are computed once and kept for all its rows, the
+// vertical taps once per row, and all index arithmetic is 32-bit.
 template <int V> struct ColTaps { int i0[V], i1[V]; float l0[V], l1[V]; };
 
 template <int V>
@@ -103,27 +107,35 @@ __device__ __forceinline__ ColTaps<V> col_taps(const LossArgs& a, int x) {
     return c;
 }
 
-// The pixel pass of a block: adds its part of sum w to accw and of sum w * pixel loss to accl, and
-// writes the image gradient BEFORE the division by the weight sum, gscale * w * d(loss)/d(pred):
-// the sum is only known once every block is done, so 1 / sum w is handed to the caller
-// (losses[3]) and multiplied in together with the upstream gradient.
-// A wave works on two adjacent prediction rows at a time, its lanes on V consecutive pixels of
-// up to two column groups: 4 items whose loads are all issued first, from clamped (always valid)
-// addresses; results of items outside the grid are dropped afterwards -- no load sits behind a
-// branch.  When the target is smaller than the prediction and its rows fit (TW <= SROW), the
-// wave first copies the four target rows the two prediction rows interpolate between into its
-// own LDS slice with coalesced loads and takes the resize taps from there: per-lane gathers
-// from global memory cost an instruction per tap and bound the pass otherwise.
+// per-lane view of one station for the backward pass: window and gradient coefficient
+struct StationLane { int x0, x1, y0, y1; float coef; };
+
+// One pass over the prediction grid, forward (BWD = false) or backward (BWD = true).
+//  forward: adds the block's part of sum w to accw and of sum w * pixel loss to accl, and notes
+//           in `bad` whether a prediction value is Inf / NaN; writes nothing.
+//  backward: writes d total / d pred of every pixel, complete: gimg * w * d(pixel loss)/d(pred)
+//           plus, for every station whose window covers the pixel, that station's coefficient
+//           (added in registers, in station order, before the one store of the pixel: no atomics,
+//           no second kernel, bit-reproducible).
+// A wave works on two adjacent prediction rows at a time: 4 items (2 rows x 2 column groups)
+// whose loads are all issued first, from clamped (always valid) addresses; results of items outside
+// the grid are dropped afterwards -- no load sits behind a branch.  When the target is smaller
+// than the prediction and its rows fit (TW <= SROW), the wave first copies the four target rows
+// the two prediction rows interpolate between into its own LDS slice with coalesced loads and
+// takes the resize taps from there: per-lane gathers from global memory cost an instruction per
+// tap and bound the pass otherwise.
 constexpr int SROW = 512;
-template <int V>
-__device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, float gscale, float* __restrict__ dpred,
-                                           float& accw, float& accl) {
+template <int V, bool BWD>
+__device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, float gimg, float gstn,
+                                           const float* __restrict__ sdiff, float* __restrict__ dpred,
+                                           float& accw, float& accl, bool& bad) {
     __shared__ float srow[NT / 64][4][SROW];
     const bool same = a.TH == a.H && a.TW == a.W;
     const bool staged = !same && a.TW <= SROW;
     const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6, wave = (int)blockIdx.x * (NT / 64) + wl;
     const int nwaves = pixel_blocks * (NT / 64), rows = a.B * a.H, wv = a.W / V;
     const int npairs = (rows + 1) >> 1;
+    const int half = a.ksize / 2;
     for (int xb = 0; xb < wv; xb += 128) {
         int xv[2];
         bool xin[2];
@@ -141,12 +153,13 @@ __device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, 
             size_t off[4];
             AxisW ay[2];
             const float* tp[2];
-            int yy[2];
+            int yy[2], bb[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int rr = 2 * pr + j;
                 const int r = rr < rows ? rr : rows - 1;
                 const int b = r / a.H;
+                bb[j] = b;
                 yy[j] = r - b * a.H;
                 tp[j] = a.target + (size_t)b * a.TH * a.TW;
                 ay[j] = axis_w(yy[j], a.TH, a.H);
@@ -155,7 +168,7 @@ __device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, 
                     const int u = 2 * j + i;
                     ok[u] = rr < rows && xin[i];
                     off[u] = (size_t)r * a.W + xv[i] * V;
-                    if (V == 4) {
+                    if constexpr (V == 4) {
                         const float4 v = *reinterpret_cast<const float4*>(a.pred + off[u]);
                         pv[u][0] = v.x; pv[u][1] = v.y; pv[u][2] = v.z; pv[u][3] = v.w;
                     } else {
@@ -183,7 +196,7 @@ __device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, 
                 for (int i = 0; i < 2; ++i) {
                     const int u = 2 * j + i;
                     if (same) {
-                        if (V == 4) {
+                        if constexpr (V == 4) {
                             const float4 v = *reinterpret_cast<const float4*>(tp[j] + (size_t)yy[j] * a.W + xv[i] * V);
                             t[u][0] = v.x; t[u][1] = v.y; t[u][2] = v.z; t[u][3] = v.w;
                         } else {
@@ -201,97 +214,173 @@ __device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, 
                         else taps(tp[j] + ay[j].i0 * a.TW, tp[j] + ay[j].i1 * a.TW);
                     }
                 }
+            float g[4][V];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                float g[V];
                 float pw = 0.f, pl = 0.f;
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     const float w = pixel_weight(a, t[u][e]);
                     const float d = pv[u][e] - t[u][e];
-                    pw += w;
-                    pl += (a.image_metric == 0 ? d * d : fabsf(d)) * w;
-                    g[e] = gscale * w * (a.image_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+                    if (BWD) {
+                        g[u][e] = gimg * w * (a.image_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+                    } else {
+                        pw += w;
+                        pl += (a.image_metric == 0 ? d * d : fabsf(d)) * w;
+                        bad |= ok[u] && !(fabsf(pv[u][e]) <= 3.402823466e38f);
+                    }
                 }
-                accw += ok[u] ? pw : 0.f;
-                accl += ok[u] ? pl : 0.f;
-                if (ok[u]) {
-                    if (V == 4) *reinterpret_cast<float4*>(dpred + off[u]) = make_float4(g[0], g[1], g[2], g[3]);
-                    else dpred[off[u]] = g[0];
+                if (!BWD) {
+                    accw += ok[u] ? pw : 0.f;
+                    accl += ok[u] ? pl : 0.f;
                 }
+            }
+            if (BWD) {
+                // stations of the two rows' samples, 64 at a time, one per lane: window, coefficient,
+                // then every station whose window holds one of the rows is handed round the wave
+                if (a.S > 0 && gstn != 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int s0 = a.offsets[bb[j]], s1 = a.offsets[bb[j] + 1];
+                        for (int base = s0; base < s1; base += 64) {
+                            const int s = base + lane;
+                            const int sc = s < s1 ? s : s1 - 1;
+                            const int px = a.pos[2 * sc], py = a.pos[2 * sc + 1];
+                            StationLane st;
+                            st.y0 = max(0, py - half); st.y1 = min(a.H, py + half + 1);
+                            st.x0 = max(0, px - half); st.x1 = min(a.W, px + half + 1);
+                            const int n = (st.y1 > st.y0 && st.x1 > st.x0) ? (st.y1 - st.y0) * (st.x1 - st.x0) : 0;
+                            const bool hit = s < s1 && n > 0 && yy[j] >= st.y0 && yy[j] < st.y1 && 2 * pr + j < rows;
+                            float d = 0.f;
+                            if (sdiff) d = sdiff[sc];
+                            unsigned long long m = __ballot(hit);
+                            if (!sdiff && m) {
+                                // no saved differences: the window means of the hit stations are gathered again
+                                unsigned long long mm = m;
+                                while (mm) {
+                                    const int l = __builtin_ctzll(mm);
+                                    mm &= mm - 1;
+                                    const int qx0 = __shfl(st.x0, l, 64), qy0 = __shfl(st.y0, l, 64);
+                                    const int qx1 = __shfl(st.x1, l, 64), qy1 = __shfl(st.y1, l, 64);
+                                    const int ww = qx1 - qx0, nn = ww * (qy1 - qy0);
+                                    float sum = 0.f;
+                                    for (int i2 = lane; i2 < nn; i2 += 64)
+                                        sum += a.pred[((size_t)bb[j] * a.H + qy0 + i2 / ww) * a.W + qx0 + i2 % ww];
+                                    sum = wave_sum(sum);
+                                    const float dd = sum / (float)nn - a.runoff[base + l];
+                                    if (lane == l) d = dd;
+                                }
+                            }
+                            const float gp = a.station_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+                            st.coef = n > 0 ? gstn * gp / (float)n : 0.f;
+                            while (m) {
+                                const int l = __builtin_ctzll(m);
+                                m &= m - 1;
+                                const int qx0 = __shfl(st.x0, l, 64), qx1 = __shfl(st.x1, l, 64);
+                                const float qc = __shfl(st.coef, l, 64);
+#pragma unroll
+                                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                    for (int e = 0; e < V; ++e) {
+                                        const int x = xv[i] * V + e;
+                                        g[2 * j + i][e] += (x >= qx0 && x < qx1) ? qc : 0.f;
+                                    }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) {
+                        if constexpr (V == 4) *reinterpret_cast<float4*>(dpred + off[u]) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
+                        else dpred[off[u]] = g[u][0];
+                    }
             }
         }
     }
 }
 
-// pass 1: one read of pred and target; the unnormalised image gradient goes to dpred, the
-// block's partial sums to the workspace; the station blocks gather their window means.
+// Forward: one read of pred and target.  Pixel blocks reduce the weighted pixel loss (and look for
+// Inf / NaN in pred: the training loop's prediction check, src/train.py:198, without a pass of its
+// own), station blocks gather the k x k window means (one wavefront per station, lanes over the
+// window, shuffle reduction) and keep mean - runoff per station for the backward pass.  Every block
+// leaves its partial sums in the workspace; the block that arrives last folds them, in a fixed
+// order, into the three losses and the two scalars the backward pass divides by.
 template <int V>
-__global__ __launch_bounds__(NT) void loss_main_kernel(LossArgs a, double* __restrict__ ws, float* __restrict__ dpred,
-                                                       int pixel_blocks) {
+__global__ __launch_bounds__(NT) void loss_fwd_kernel(LossArgs a, double* __restrict__ ws, float* losses, float* scal,
+                                                      float* __restrict__ sdiff, int* __restrict__ nan_flag,
+                                                      int pixel_blocks, int station_blocks) {
     __shared__ double smd[4];
+    __shared__ int s_last;
     if ((int)blockIdx.x < pixel_blocks) {
         float accw = 0.f, accl = 0.f;
-        pixel_pass<V>(a, pixel_blocks, a.image_weight, dpred, accw, accl);
+        bool bad = false;
+        pixel_pass<V, false>(a, pixel_blocks, 0.f, 0.f, nullptr, nullptr, accw, accl, bad);
         const double sw = block_sum_256_d((double)accw, smd);
         const double sl = block_sum_256_d((double)accl, smd);
         if (threadIdx.x == 0) { ws[WS_W + blockIdx.x] = sw; ws[WS_L + blockIdx.x] = sl; }
+        if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
     } else {
-        const int sb = (int)blockIdx.x - pixel_blocks, nsb = (int)gridDim.x - pixel_blocks;
+        const int sb = (int)blockIdx.x - pixel_blocks;
         const int lane = threadIdx.x & 63;
         double tl = 0.0, tc = 0.0;
-        for (int s = sb * (NT / 64) + (threadIdx.x >> 6); s < a.S; s += nsb * (NT / 64)) {
+        for (int s = sb * (NT / 64) + (threadIdx.x >> 6); s < a.S; s += station_blocks * (NT / 64)) {
             const int b = sample_of(a.offsets, a.B, s);
             int n, x0, y0, ww;
             const float m = station_mean(a, b, a.pos[2 * s], a.pos[2 * s + 1], lane, &n, &x0, &y0, &ww);
-            if (n > 0 && lane == 0) {
-                const float d = m - a.runoff[s];
-                tl += (double)(a.station_metric == 0 ? d * d : fabsf(d));
-                tc += 1.0;
+            const float d = n > 0 ? m - a.runoff[s] : 0.f;
+            if (lane == 0) {
+                if (sdiff) sdiff[s] = d;
+                if (n > 0) {
+                    tl += (double)(a.station_metric == 0 ? d * d : fabsf(d));
+                    tc += 1.0;
+                }
             }
         }
         tl = block_sum_256_d(tl, smd);
         tc = block_sum_256_d(tc, smd);
         if (threadIdx.x == 0) { ws[WS_ST + sb] = tl; ws[WS_SC + sb] = tc; }
     }
+    // arrival: thread 0's partials are released with its ticket; the last block acquires everyone's
+    if (threadIdx.x == 0) {
+        int* arrived = reinterpret_cast<int*>(ws + WS_ARRIVED);
+        const int ticket = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const double cnt = fold_partials(ws + WS_SC, station_blocks, smd);
+    const double sw = fold_partials(ws + WS_W, pixel_blocks, smd);
+    const double sl = fold_partials(ws + WS_L, pixel_blocks, smd);
+    const double tl = fold_partials(ws + WS_ST, station_blocks, smd);
+    if (threadIdx.x == 0) {
+        const float img = (float)(sl / sw);
+        const float stn = cnt > 0.0 ? (float)(tl / cnt) : 0.f;
+        losses[1] = img;
+        losses[2] = stn;
+        losses[0] = a.image_weight * img + a.station_weight * stn;
+        if (scal != losses + 3) losses[3] = 1.0f;      // the caller gets the finished gradient (see loss_fused)
+        scal[0] = (float)(1.0 / sw);
+        scal[1] = cnt > 0.0 ? (float)(1.0 / cnt) : 0.f;
+        __hip_atomic_store(reinterpret_cast<int*>(ws + WS_ARRIVED), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-// pass 2: block 0 folds the partials into the three losses and 1 / sum w; every block scatters the
-// station gradient of its stations (windows may overlap -> atomics) onto the image gradient,
-// multiplied by sum w because the caller's 1 / sum w factor applies to all of dpred.
-__global__ __launch_bounds__(NT) void loss_finish_kernel(LossArgs a, const double* __restrict__ ws,
-                                                         float* __restrict__ losses, float* __restrict__ dpred,
-                                                         int pixel_blocks, int station_blocks) {
-    __shared__ double smd[4];
-    const double cnt_d = fold_partials(ws + WS_SC, station_blocks, smd);
-    const double sw = fold_partials(ws + WS_W, pixel_blocks, smd);
-    if (blockIdx.x == 0) {
-        const double sl = fold_partials(ws + WS_L, pixel_blocks, smd);
-        const double tl = fold_partials(ws + WS_ST, station_blocks, smd);
-        if (threadIdx.x == 0) {
-            const float img = (float)(sl / sw);
-            const float stn = cnt_d > 0.0 ? (float)(tl / cnt_d) : 0.f;
-            losses[1] = img;
-            losses[2] = stn;
-            losses[0] = a.image_weight * img + a.station_weight * stn;
-            losses[3] = (float)(1.0 / sw);
-        }
-    }
-    const float cnt = (float)cnt_d;
-    if (cnt <= 0.f) return;
-    const float swf = (float)sw;
-    const int lane = threadIdx.x & 63;
-    for (int s = (int)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); s < a.S; s += (int)gridDim.x * (NT / 64)) {
-        const int b = sample_of(a.offsets, a.B, s);
-        int n, x0, y0, ww;
-        const float m = station_mean(a, b, a.pos[2 * s], a.pos[2 * s + 1], lane, &n, &x0, &y0, &ww);
-        if (n <= 0) continue;
-        const float d = m - a.runoff[s];
-        const float g = a.station_metric == 0 ? 2.0f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        const float coef = swf * (a.station_weight * g / ((float)n * cnt));
-        for (int i = lane; i < n; i += 64)
-            unsafeAtomicAdd(&dpred[((size_t)b * a.H + y0 + i / ww) * a.W + x0 + i % ww], coef);
-    }
+// Backward: d total / d pred, complete, in one pass and one store per pixel:
+//   upstream * (image_weight / sum w * w * d(pixel loss) + station_weight / count * sum over the
+//   stations whose window holds the pixel of d(station loss) / window size).
+// scal = {1 / sum w, 1 / count or 0} as the forward pass left them; `upstream` is a device scalar
+// (the gradient arriving at the total loss) or null for 1.
+template <int V>
+__global__ __launch_bounds__(NT) void loss_bwd_kernel(LossArgs a, const float* __restrict__ scal,
+                                                      const float* __restrict__ upstream, const float* __restrict__ sdiff,
+                                                      float* __restrict__ dpred, int pixel_blocks) {
+    const float up = upstream ? upstream[0] : 1.0f;
+    const float gimg = up * a.image_weight * scal[0];
+    const float gstn = up * a.station_weight * scal[1];
+    float accw = 0.f, accl = 0.f;
+    bool bad = false;
+    pixel_pass<V, true>(a, pixel_blocks, gimg, gstn, sdiff, dpred, accw, accl, bad);
 }
 
 __global__ void bce_reduce_kernel(const float* __restrict__ x, long long n, float label_c,
@@ -487,6 +576,101 @@ int static_scratch(hipStream_t stream, double** out) {
 }
 }  // namespace
 
+namespace {
+struct LossPlan { LossArgs a; bool vec; int pb, sb; };
+
+int loss_plan(const char* who, LossPlan& q, const float* pred, const float* target, const int* pos, const float* runoff,
+              const int* offsets, int S, int B, int H, int W, int TH, int TW, int image_metric, float nonzero_weight,
+              float zero_threshold, int ksize, int station_metric, float image_weight, float station_weight,
+              const float* dpred) {
+    SF_REQUIRE(pred && target, "%s: null argument", who);
+    SF_REQUIRE(B > 0 && H > 0 && W > 0 && TH > 0 && TW > 0 && S >= 0, "%s: bad shape", who);
+    SF_REQUIRE(S == 0 || (pos && runoff && offsets), "%s: stations without arrays", who);
+    SF_REQUIRE(ksize >= 1, "%s: kernel_size %d", who, ksize);
+    SF_REQUIRE((image_metric == 0 || image_metric == 1) && (station_metric == 0 || station_metric == 1), "%s: metric", who);
+    LossArgs& a = q.a;
+    a.pred = pred; a.target = target; a.pos = pos; a.runoff = runoff; a.offsets = offsets;
+    a.S = S; a.B = B; a.H = H; a.W = W; a.TH = TH; a.TW = TW; a.image_metric = image_metric; a.ksize = ksize;
+    a.station_metric = station_metric; a.nonzero_weight = nonzero_weight; a.zero_threshold = zero_threshold;
+    a.image_weight = image_weight; a.station_weight = station_weight;
+    const long long total = (long long)B * H * W;
+    q.vec = W % 4 == 0 && ((uintptr_t)pred | (uintptr_t)dpred | (uintptr_t)target) % 16 == 0 &&
+            (TW % 4 == 0 || TH != H || TW != W);
+    SF_REQUIRE((long long)B * H < 0x7fffffffLL && total < (1LL << 40), "%s: batch too large", who);
+    // a wave per pair of rows at a time
+    const long long rows = (long long)B * H;
+    int pb = (int)((rows + 7) / 8); if (pb > LP) pb = LP; if (pb < 1) pb = 1;
+    int sb = (S + 3) / 4; if (sb > LS) sb = LS; if (sb < 1) sb = 1;
+    q.pb = pb; q.sb = sb;
+    return SF_OK;
+}
+
+int loss_fwd_launch(const LossPlan& q, float* losses, float* scal, float* sdiff, int* nan_flag, double* ws, hipStream_t s) {
+    if (q.vec) hipLaunchKernelGGL(loss_fwd_kernel<4>, dim3(q.pb + q.sb), dim3(NT), 0, s, q.a, ws, losses, scal, sdiff, nan_flag, q.pb, q.sb);
+    else hipLaunchKernelGGL(loss_fwd_kernel<1>, dim3(q.pb + q.sb), dim3(NT), 0, s, q.a, ws, losses, scal, sdiff, nan_flag, q.pb, q.sb);
+    SF_LAUNCH_CHECK("sf_image_station_loss_fwd");
+    return SF_OK;
+}
+
+int loss_bwd_launch(const LossPlan& q, const float* scal, const float* upstream, const float* sdiff, float* dpred,
+                    hipStream_t s) {
+    if (q.vec) hipLaunchKernelGGL(loss_bwd_kernel<4>, dim3(q.pb), dim3(NT), 0, s, q.a, scal, upstream, sdiff, dpred, q.pb);
+    else hipLaunchKernelGGL(loss_bwd_kernel<1>, dim3(q.pb), dim3(NT), 0, s, q.a, scal, upstream, sdiff, dpred, q.pb);
+    SF_LAUNCH_CHECK("sf_image_station_loss_bwd");
+    return SF_OK;
+}
+}  // namespace
+
+extern "C" int sf_image_station_loss_fwd(const float* pred, const float* target, const int* pos, const float* runoff,
+                                         const int* offsets, int S, int B, int H, int W, int TH, int TW,
+                                         int image_metric, float nonzero_weight, float zero_threshold, int ksize,
+                                         int station_metric, float image_weight, float station_weight, float* losses,
+                                         float* station_diff, int* nan_flag, double* ws, void* stream) {
+    SF_REQUIRE(losses && ws, "sf_image_station_loss_fwd: null argument");
+    LossPlan q;
+    const int rc = loss_plan("sf_image_station_loss_fwd", q, pred, target, pos, runoff, offsets, S, B, H, W, TH, TW,
+                             image_metric, nonzero_weight, zero_threshold, ksize, station_metric, image_weight,
+                             station_weight, nullptr);
+    if (rc != SF_OK) return rc;
+    return loss_fwd_launch(q, losses, losses + 3, station_diff, nan_flag, ws, (hipStream_t)stream);
+}
+
+extern "C" int sf_image_station_loss_bwd(const float* pred, const float* target, const int* pos, const float* runoff,
+                                         const int* offsets, int S, int B, int H, int W, int TH, int TW,
+                                         int image_metric, float nonzero_weight, float zero_threshold, int ksize,
+                                         int station_metric, float image_weight, float station_weight,
+                                         const float* upstream, const float* station_diff,
+                                         const float* fwd_losses, float* dpred, void* stream) {
+    SF_REQUIRE(dpred && fwd_losses, "sf_image_station_loss_bwd: null argument");
+    LossPlan q;
+    const int rc = loss_plan("sf_image_station_loss_bwd", q, pred, target, pos, runoff, offsets, S, B, H, W, TH, TW,
+                             image_metric, nonzero_weight, zero_threshold, ksize, station_metric, image_weight,
+                             station_weight, dpred);
+    if (rc != SF_OK) return rc;
+    return loss_bwd_launch(q, fwd_losses + 3, upstream, station_diff, dpred, (hipStream_t)stream);
+}
+
+// forward + backward back to back with an upstream gradient of 1; `zero_counter`: the workspace is
+// the caller's and may hold anything, so its arrival counter is cleared on the stream first
+static int loss_fused(const char* who, const float* pred, const float* target, const int* pos, const float* runoff,
+                      const int* offsets, int S, int B, int H, int W, int TH, int TW, int image_metric,
+                      float nonzero_weight, float zero_threshold, int ksize, int station_metric, float image_weight,
+                      float station_weight, float* losses, float* dpred, double* ws, bool zero_counter, hipStream_t s) {
+    SF_REQUIRE(losses && dpred && ws, "%s: null argument", who);
+    LossPlan q;
+    int rc = loss_plan(who, q, pred, target, pos, runoff, offsets, S, B, H, W, TH, TW, image_metric, nonzero_weight,
+                       zero_threshold, ksize, station_metric, image_weight, station_weight, dpred);
+    if (rc != SF_OK) return rc;
+    if (zero_counter && hipMemsetAsync(ws + WS_ARRIVED, 0, sizeof(double), s) != hipSuccess) {
+        sf_set_error("%s: clearing the workspace counter failed", who);
+        return SF_ELAUNCH;
+    }
+    float* scal = reinterpret_cast<float*>(ws + WS_SCAL);      // the two divisors travel through the workspace
+    rc = loss_fwd_launch(q, losses, scal, nullptr, nullptr, ws, s);
+    if (rc != SF_OK) return rc;
+    return loss_bwd_launch(q, scal, nullptr, nullptr, dpred, s);
+}
+
 extern "C" int sf_image_station_loss_static(const float* pred, const float* target, const int* pos, const float* runoff,
                                             const int* offsets, int S, int B, int H, int W, int TH, int TW,
                                             int image_metric, float nonzero_weight, float zero_threshold, int ksize,
@@ -501,11 +685,12 @@ extern "C" int sf_image_station_loss_static(const float* pred, const float* targ
     double* ws = nullptr;
     const int rc = static_scratch((hipStream_t)stream, &ws);
     if (rc != SF_OK) return rc;
-    // every call writes all the partial-sum slots it later reads (nothing has to start at zero), so
-    // the previous call's contents of the array are never seen
-    return sf_image_station_loss(pred, target, pos, runoff, offsets, S, B, H, W, TH, TW, image_metric, nonzero_weight,
-                                 zero_threshold, ksize, station_metric, image_weight, station_weight, losses, dpred, ws,
-                                 stream);
+    // every call writes all the partial-sum slots it later reads, and the arrival counter -- zero
+    // when the library is loaded -- is put back to zero by the block that folds the sums, so the
+    // previous call's contents of the array are never seen and nothing has to be cleared here
+    return loss_fused("sf_image_station_loss_static", pred, target, pos, runoff, offsets, S, B, H, W, TH, TW,
+                      image_metric, nonzero_weight, zero_threshold, ksize, station_metric, image_weight, station_weight,
+                      losses, dpred, ws, false, (hipStream_t)stream);
 }
 
 extern "C" int sf_image_station_loss(const float* pred, const float* target, const int* pos, const float* runoff,
@@ -513,30 +698,9 @@ extern "C" int sf_image_station_loss(const float* pred, const float* target, con
                                      float nonzero_weight, float zero_threshold, int ksize, int station_metric,
                                      float image_weight, float station_weight, float* losses, float* dpred, double* ws,
                                      void* stream) {
-    SF_REQUIRE(pred && target && losses && dpred && ws, "sf_image_station_loss: null argument");
-    SF_REQUIRE(B > 0 && H > 0 && W > 0 && TH > 0 && TW > 0 && S >= 0, "sf_image_station_loss: bad shape");
-    SF_REQUIRE(S == 0 || (pos && runoff && offsets), "sf_image_station_loss: stations without arrays");
-    SF_REQUIRE(ksize >= 1, "sf_image_station_loss: kernel_size %d", ksize);
-    SF_REQUIRE((image_metric == 0 || image_metric == 1) && (station_metric == 0 || station_metric == 1), "sf_image_station_loss: metric");
-    hipStream_t s = (hipStream_t)stream;
-    LossArgs a;
-    a.pred = pred; a.target = target; a.pos = pos; a.runoff = runoff; a.offsets = offsets;
-    a.S = S; a.B = B; a.H = H; a.W = W; a.TH = TH; a.TW = TW; a.image_metric = image_metric; a.ksize = ksize;
-    a.station_metric = station_metric; a.nonzero_weight = nonzero_weight; a.zero_threshold = zero_threshold;
-    a.image_weight = image_weight; a.station_weight = station_weight;
-    const long long total = (long long)B * H * W;
-    const bool vec = W % 4 == 0 && ((uintptr_t)pred | (uintptr_t)dpred | (uintptr_t)target) % 16 == 0 &&
-                     (TW % 4 == 0 || TH != H || TW != W);
-    SF_REQUIRE((long long)B * H < 0x7fffffffLL && total < (1LL << 40), "sf_image_station_loss: batch too large");
-    // a wave per pair of rows at a time
-    const long long rows = (long long)B * H;
-    int pb = (int)((rows + 7) / 8); if (pb > LP) pb = LP; if (pb < 1) pb = 1;
-    int sb = (S + 3) / 4; if (sb > LS) sb = LS; if (sb < 1) sb = 1;
-    if (vec) hipLaunchKernelGGL(loss_main_kernel<4>, dim3(pb + sb), dim3(NT), 0, s, a, ws, dpred, pb);
-    else hipLaunchKernelGGL(loss_main_kernel<1>, dim3(pb + sb), dim3(NT), 0, s, a, ws, dpred, pb);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(sb), dim3(NT), 0, s, a, ws, losses, dpred, pb, sb);
-    SF_LAUNCH_CHECK("sf_image_station_loss");
-    return SF_OK;
+    return loss_fused("sf_image_station_loss", pred, target, pos, runoff, offsets, S, B, H, W, TH, TW, image_metric,
+                      nonzero_weight, zero_threshold, ksize, station_metric, image_weight, station_weight, losses, dpred,
+                      ws, true, (hipStream_t)stream);
 }
 
 extern "C" int sf_bce_logits(const float* x, long long n, float label, const float* labels, float* loss, float* dx,

@@ -737,24 +737,28 @@ def pack_stations(positions: Sequence[torch.Tensor], runoffs: Sequence[torch.Ten
 
 
 class ImageStationLossFn(torch.autograd.Function):
-    """ImageLoss + StationLoss + their weighted sum (src/loss.py:47-70,116-160,227-230), forward
-    and backward in one launch sequence.  Returns a [3] tensor: total, image, station; only
-    `total` carries a gradient."""
+    """ImageLoss + StationLoss + their weighted sum (src/loss.py:47-70,116-160,227-230): one launch
+    forward (losses; optionally the Inf/NaN check of the predictions, src/train.py:198), one launch
+    backward (the complete gradient, upstream factor included).  Returns a [3] tensor: total,
+    image, station; only `total` carries a gradient."""
 
     @staticmethod
-    def forward(ctx, pred, target, pos, runoff, offsets, S, cfg):
-        (image_metric, nonzero_weight, zero_threshold, ksize, station_metric, iw, sw) = cfg
-        losses, dpred = ops.image_station_loss(pred.contiguous().float(), target.contiguous().float(), pos, runoff,
-                                               offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
-                                               station_metric, iw, sw)
-        ctx.save_for_backward(dpred, losses)
+    def forward(ctx, pred, target, pos, runoff, offsets, S, cfg, nan_flag=None):
+        p, t = pred.contiguous().float(), target.contiguous().float()
+        need = ctx.needs_input_grad[0]
+        losses, sdiff = ops.image_station_loss_fwd(p, t, pos, runoff, offsets, S, *cfg, nan_flag=nan_flag,
+                                                   keep_for_backward=need)
+        if need:
+            ctx.save_for_backward(p, t, pos, runoff, offsets, losses, sdiff)
+            ctx.S, ctx.cfg = S, cfg
         return losses[:3]
 
     @staticmethod
     def backward(ctx, g):
-        # the kernel leaves the division by the weight sum (losses[3] = its inverse) to this product
-        dpred, losses = ctx.saved_tensors
-        return dpred * (g[0] * losses[3]), None, None, None, None, None, None
+        p, t, pos, runoff, offsets, losses, sdiff = ctx.saved_tensors
+        up = g if g.is_contiguous() and g.dtype == torch.float32 else g.contiguous().float()    # element 0: d / d total
+        dpred = ops.image_station_loss_bwd(p, t, pos, runoff, offsets, ctx.S, *ctx.cfg, losses, sdiff=sdiff, upstream=up)
+        return dpred, None, None, None, None, None, None, None
 
 
 class BceLogitsFn(torch.autograd.Function):

@@ -426,7 +426,11 @@ class CombinedLoss(nn.Module):
         scfg = config.get("stations", {})
         self.station_loss = StationLoss(kernel_size=scfg.get("kernel_size", 3), metric=scfg.get("metric", "MSE"))
 
-    def forward(self, predictions, targets, station_positions=None, station_runoffs=None) -> Dict[str, torch.Tensor]:
+    def forward(self, predictions, targets, station_positions=None, station_runoffs=None, nan_flag=None
+                ) -> Dict[str, torch.Tensor]:
+        """nan_flag (not in the reference's signature): an int32 [1] device tensor that is OR-ed with
+        1 when the predictions hold Inf / NaN -- the check of src/train.py:198 done by the loss pass,
+        which reads every prediction anyway."""
         _need_cuda(predictions, "CombinedLoss")
         if station_positions is not None and station_runoffs is not None:
             pos, run, offs, S = SF.pack_stations(station_positions, station_runoffs, predictions.device)
@@ -435,6 +439,6 @@ class CombinedLoss(nn.Module):
         il, sl = self.image_loss, self.station_loss
         cfg = (_METRIC[il.metric], float(il.nonzero_weight), float(il.zero_threshold), int(sl.kernel_size),
                _METRIC[sl.metric], float(self.image_weight), float(self.station_weight))
-        out = SF.ImageStationLossFn.apply(predictions, targets.to(predictions.device), pos, run, offs, S, cfg)
+        out = SF.ImageStationLossFn.apply(predictions, targets.to(predictions.device), pos, run, offs, S, cfg, nan_flag)
         # `total` carries the gradient of the weighted sum; the two components are reported values
         return {"total": out[0], "image": out[1].detach(), "station": out[2].detach()}

@@ -75,7 +75,7 @@ EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
            "sf_conv_k1_fwd", "sf_conv_k1_fwd_ws", "sf_conv_k1_fwd_workspace_bytes", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
-           "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss", "sf_image_station_loss_static",
+           "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss", "sf_image_station_loss_fwd", "sf_image_station_loss_bwd", "sf_image_station_loss_static",
            "sf_bce_logits", "sf_adam", "sf_adam_begin", "sf_adam_guarded", "sf_nan_inf_flag", "sf_dataset_plane_stats", "sf_dataset_transform",
            "sf_gather_frames", "sf_date_image_metrics", "sf_date_image_metrics_workspace_bytes", "sf_bn_relu_fwd",
            "sf_relu_dropout_fwd", "sf_relu_dropout_bwd", "sf_gru_save_floats", "sf_gru_fwd", "sf_gru_bwd",
@@ -1046,14 +1046,66 @@ def lonlat_to_pixel(lon: torch.Tensor, lat: torch.Tensor, region, W: int, H: int
     return px, py
 
 
-def image_station_loss(pred, target, pos, runoff, offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
-                       station_metric, image_weight, station_weight):
-    """Returns (losses f32 [4] = total, image, station, 1 / weight sum; dpred): the gradient of
-    the total loss with respect to pred is dpred * losses[3]."""
+_LOSS_WS: dict = {}
+
+
+def _loss_workspace(device: torch.device) -> torch.Tensor:
+    """The loss workspace of (device, current stream): allocated once, zero (the arrival counter in
+    its last double has to start at zero and every forward call leaves it so); forward and backward
+    of one loss call are both issued on that stream, so its calls never overlap."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
+    ws = _LOSS_WS.get(key)
+    if ws is None:
+        ws = _LOSS_WS[key] = torch.zeros(LOSS_WS_DOUBLES, device=device, dtype=torch.float64)
+    return ws
+
+
+def _loss_args(pred, target, pos, runoff, offsets):
     _dev(pred, target, pos, runoff, offsets,
          dtypes=[torch.float32, torch.float32, torch.int32, torch.float32, torch.int32])
     B, _, H, W = pred.shape
-    TH, TW = target.shape[-2], target.shape[-1]
+    return B, H, W, target.shape[-2], target.shape[-1]
+
+
+def image_station_loss_fwd(pred, target, pos, runoff, offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
+                           station_metric, image_weight, station_weight, nan_flag=None, keep_for_backward=True):
+    """One launch: (losses f32 [5] = total, image, station, 1 / weight sum, 1 / stations counted;
+    station differences [S] for image_station_loss_bwd, or None).  nan_flag: int32 [1] that is OR-ed
+    with 1 when pred holds Inf / NaN."""
+    B, H, W, TH, TW = _loss_args(pred, target, pos, runoff, offsets)
+    _dev(nan_flag, dtypes=[torch.int32])
+    losses = torch.empty(5, device=pred.device, dtype=torch.float32)
+    sdiff = torch.empty(max(S, 1), device=pred.device, dtype=torch.float32) if keep_for_backward else None
+    ws = _loss_workspace(pred.device)
+    _check(lib().sf_image_station_loss_fwd(_p(pred), _p(target), _p(pos), _p(runoff), _p(offsets), S, B, H, W, TH, TW,
+                                           image_metric, _c_f(nonzero_weight), _c_f(zero_threshold), ksize,
+                                           station_metric, _c_f(image_weight), _c_f(station_weight), _p(losses),
+                                           _p(sdiff), _p(nan_flag), _p(ws), _stream()), "sf_image_station_loss_fwd")
+    return losses, sdiff
+
+
+def image_station_loss_bwd(pred, target, pos, runoff, offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
+                           station_metric, image_weight, station_weight, fwd_losses, sdiff=None, upstream=None):
+    """One launch: upstream * d total / d pred, complete.  fwd_losses: the [5] tensor of the forward
+    call; sdiff: its station differences (None: gathered again); upstream: f32 device scalar or
+    None = 1."""
+    B, H, W, TH, TW = _loss_args(pred, target, pos, runoff, offsets)
+    _dev(upstream, sdiff, fwd_losses, dtypes=[torch.float32, torch.float32, torch.float32])
+    if fwd_losses.numel() < 5:
+        raise RuntimeError("image_station_loss_bwd: fwd_losses must be the 5 floats of image_station_loss_fwd")
+    dpred = torch.empty_like(pred)
+    _check(lib().sf_image_station_loss_bwd(_p(pred), _p(target), _p(pos), _p(runoff), _p(offsets), S, B, H, W, TH, TW,
+                                           image_metric, _c_f(nonzero_weight), _c_f(zero_threshold), ksize,
+                                           station_metric, _c_f(image_weight), _c_f(station_weight), _p(upstream),
+                                           _p(sdiff), _p(fwd_losses), _p(dpred), _stream()), "sf_image_station_loss_bwd")
+    return dpred
+
+
+def image_station_loss(pred, target, pos, runoff, offsets, S, image_metric, nonzero_weight, zero_threshold, ksize,
+                       station_metric, image_weight, station_weight):
+    """sf_image_station_loss (forward and backward back to back, upstream gradient 1): returns
+    (losses f32 [4] = total, image, station, 1; dpred = d total / d pred)."""
+    B, H, W, TH, TW = _loss_args(pred, target, pos, runoff, offsets)
     losses = torch.empty(4, device=pred.device, dtype=torch.float32)
     dpred = torch.empty_like(pred)
     ws = torch.empty(LOSS_WS_DOUBLES, device=pred.device, dtype=torch.float64)

@@ -385,8 +385,9 @@ class Trainer:
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_amp):
             # the input check of src/train.py:193 rides on the encoder's layout pass
             pred = self.model(images, nan_flag=self.nan_flags[_FLAG_IMAGES:_FLAG_IMAGES + 1])
-            ops.nan_inf_flag(pred.view(-1), self.nan_flags[_FLAG_PRED:_FLAG_PRED + 1])
-            ld = self.loss_fn(pred, output_image, station_positions, station_runoffs)
+            # the prediction check of src/train.py:198 rides on the loss's forward pass
+            ld = self.loss_fn(pred, output_image, station_positions, station_runoffs,
+                              nan_flag=self.nan_flags[_FLAG_PRED:_FLAG_PRED + 1])
             loss_g = ld["total"]
             if self.use_gan:
                 pred_fake = self.discriminator(pred, keep_record=d_batch)

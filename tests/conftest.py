@@ -94,7 +94,7 @@ PARTLY_NOISE_DRIVEN = ("self_attn.in_proj_bias",)
 def check_update_projection(after, before, keys, ref, tol_proj=2e-2, tol_norm=2e-3, skip=NOISE_DRIVEN):
     """Signed projections of the parameter updates (goldgen.update_projection) against the golden
     ones, both relative to the reference update's L2 norm: the norms must agree to tol_norm, the
-    projections to tol_proj (0.1 for tensors a third of whose entries are noise driven).  A
+    projections to tol_proj (0.1 for tensors a third of whose entries are noise driven; None: norms only).  A
     missing, doubled or sign-flipped step on a tensor is an error of order 1 in both; a learning
     rate, bias correction or gradient scale off by a per cent shows in the norm.  What keeps the
     projection from 1e-3 even between two correct f32 implementations is Adam itself: an entry
@@ -110,7 +110,7 @@ def check_update_projection(after, before, keys, ref, tol_proj=2e-2, tol_norm=2e
         scale = max(float(want[1]), 1e-30)
         tp = 0.1 if k.endswith(PARTLY_NOISE_DRIVEN) else tol_proj
         e_proj, e_norm = abs(got[k][0] - want[0]) / scale, abs(got[k][1] - want[1]) / scale
-        if not (e_proj <= tp and e_norm <= tol_norm):
+        if not ((tol_proj is None or e_proj <= tp) and e_norm <= tol_norm):
             bad.append(f"{k}: projection off by {e_proj:.2e}, norm by {e_norm:.2e} of the update norm {scale:.3e}")
     assert not bad, "\n".join(bad)
 

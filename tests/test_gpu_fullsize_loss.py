@@ -71,3 +71,40 @@ def test_full_size_sample_order_and_directional_derivative(sf):
     lm = float(sf.CombinedLoss(CFG)((pred - eps * d).to(DEV), tgt.to(DEV), pos, run)["total"])
     lin = 2 * eps * float((grad.double().cpu() * d.double()).sum())
     assert abs((lp - lm) - lin) <= 2e-3 * abs(lin) + 1e-6
+
+
+def test_split_forward_backward_against_the_fused_call(sf):
+    """sf_image_station_loss_fwd / _bwd (one launch each, what the autograd Function uses) against
+    sf_image_station_loss (both back to back, upstream 1): same losses bit for bit; the gradient
+    with an upstream factor is the fused gradient times that factor; with and without the saved
+    station differences; two runs are bit-identical (no atomics anywhere); the prediction check
+    sets its flag only for an Inf / NaN."""
+    import importlib
+    SF = importlib.import_module(sf.__name__ + ".functional")
+    ops = sf.ops
+    pred, tgt, pos, run = _inputs()
+    p, t = pred.to(DEV), tgt.to(DEV)
+    dpos, drun, doffs, S = SF.pack_stations(pos, run, p.device)
+    args = (p, t, dpos, drun, doffs, S, 0, 10.0, 1e-6, 5, 0, 1.0, 0.5)
+    ref_l, ref_g = ops.image_station_loss(*args)
+    assert float(ref_l[3]) == 1.0
+    flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+    losses, sdiff = ops.image_station_loss_fwd(*args, nan_flag=flag)
+    assert torch.equal(losses[:3], ref_l[:3]) and int(flag) == 0
+    losses2, _ = ops.image_station_loss_fwd(*args, nan_flag=flag)
+    assert torch.equal(losses2, losses)
+    up = torch.tensor([2.5], device=DEV)
+    g1 = ops.image_station_loss_bwd(*args, losses, sdiff=sdiff, upstream=up)
+    g2 = ops.image_station_loss_bwd(*args, losses, sdiff=None, upstream=up)
+    g3 = ops.image_station_loss_bwd(*args, losses, sdiff=sdiff, upstream=None)
+    assert torch.equal(g1, ops.image_station_loss_bwd(*args, losses, sdiff=sdiff, upstream=up))
+    close(g1, (2.5 * ref_g).cpu().numpy(), 1e-6)
+    close(g2, g1.cpu().numpy(), 1e-6)
+    assert torch.equal(g3, ref_g)
+    # a single NaN / Inf anywhere in pred raises the flag (and only then)
+    for bad in (float("nan"), float("-inf")):
+        q = p.clone()
+        q[17, 0, 399, 398] = bad
+        flag.zero_()
+        ops.image_station_loss_fwd(q, *args[1:], nan_flag=flag)
+        assert int(flag) == 1

@@ -410,8 +410,9 @@ def test_train_epoch_semantics_f32(sf, temporal, use_gan, accum, tag):
         dsd = {k: v.cpu() for k, v in tr.discriminator.state_dict().items()}
         keys = [str(k) for k in g[f"{tag}_dkeys"]]
         # the discriminator takes exactly one Adam step in these four batches (the schedule quirk):
-        # every entry moves by lr against the sign of its gradient
-        check_update_projection(dsd, d_init, keys, g[f"{tag}_dproj"], tol_proj=0.3)
+        # every entry moves by lr against the sign of its gradient: the norms are exact and the sign bits are the
+        # whole update (a projection would only sum 2 lr r_k over the few noise-level entries that flip)
+        check_update_projection(dsd, d_init, keys, g[f"{tag}_dproj"], tol_proj=None)
         check_update_signs(dsd, d_init, keys, g[f"{tag}_dsign"])
         cs = G.checksum(dsd, keys)
         np.testing.assert_allclose(np.stack([cs[k] for k in keys])[:, 1], g[f"{tag}_dsum"][:, 1], rtol=5e-4)

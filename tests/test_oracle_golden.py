@@ -347,8 +347,8 @@ def test_train_epoch_semantics(temporal, use_gan, accum, tag):
     if use_gan:
         dkeys = [str(k) for k in g[f"{tag}_dkeys"]]
         # one Adam step in these four batches: every entry moved by lr, so the norms are exact, the
-        # signs are the update, and the projection sums 2 lr r_k over the few noise-level entries
-        check_update_projection(tr.d_sd, d_init, dkeys, g[f"{tag}_dproj"], tol_proj=0.3)
+        # signs are the update (a projection would only sum 2 lr r_k over the few noise-level entries that flip)
+        check_update_projection(tr.d_sd, d_init, dkeys, g[f"{tag}_dproj"], tol_proj=None)
         check_update_signs(tr.d_sd, d_init, dkeys, g[f"{tag}_dsign"])
         keys = [str(k) for k in g[f"{tag}_dkeys"]]
         cs = G.checksum(tr.d_sd, keys)

@@ -18,4 +18,4 @@ head -n 24 gpurun_out/r3_pmc_mfma.txt
 timeout -s KILL 240 rocprofv3 --kernel-trace -d gpurun_out/r3_trace -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline > gpurun_out/r3_trace.log 2>&1 || { echo "trace failed"; tail -n 5 gpurun_out/r3_trace.log; exit 1; }
 python tools/prof_steps.py $(ls -t gpurun_out/r3_trace/*/*.db | head -n 1) 12 gpurun_out/r3a_kernel_stats.csv > gpurun_out/r3a_steps.txt 2>&1
 head -n 40 gpurun_out/r3a_steps.txt
-rm -rf gpurun_out/r3_trace gpurun_out/r3_pmcA/*/*.db.tmp
+rm -rf gpurun_out/r3_trace gpurun_out/r3_pmcA gpurun_out/r3_pmcB
