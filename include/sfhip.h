@@ -95,6 +95,11 @@ int sf_gemm_batch(int n, const sf_gemm_desc* d, const void* const* A, const void
  * for the backward pass but not read back.  Only for shapes that run on the kernel with resident
  * weights (sf_conv3x3_dot_ok: C = 64, K <= 64 in 8-channel groups, bf16 output); dot_w holds K floats. */
 int sf_conv3x3_dot_ok(int C, int K, int ldo, int out_dtype);
+/* Diagnostic (host only, no GPU work): the pixel tile th x tw the persistent bf16 3x3 kernels use on
+ * H x W images with LDS rows of row_bytes (32: the 128-output-channel shape, 64: the 64-channel
+ * shapes), and, when read_cycles is not NULL, the LDS cycles per patch-fragment read that tile
+ * costs (4.0 = free of bank conflicts).  No counterpart in the reference. */
+int sf_conv3x3_tile_shape(int H, int W, int row_bytes, int* th, int* tw, double* read_cycles);
 int sf_conv3x3_dot(const void* in, const void* wp, const float* bias, const void* aux, void* out, int N,
                    int H, int W, int C, int K, int ldo, const int* dy, const int* dx, int act, int aux_mode,
                    int out_dtype, const float* dot_w, const float* dot_b, float* dot_out, void* stream);
@@ -397,9 +402,10 @@ int sf_lonlat_to_pixel(const double* lon, const double* lat, int n, double lon_m
  *   nan_flag int32 [1], nullable: |= 1 when pred holds Inf / NaN (the prediction check of the
  *     training loop, src/train.py:198, which then needs no pass of its own); never cleared here.
  *   ws: SF_LOSS_WS_DOUBLES doubles of device scratch: per-block partial sums (folded in a fixed
- *     order by the block that finishes last: bit-reproducible losses) and in the last double an
- *     arrival counter that MUST BE ZERO before the first call using this workspace; every call
- *     leaves it zero.  Calls sharing a workspace must be ordered on one stream.
+ *     order by the block that finishes last: bit-reproducible losses) and, in its last
+ *     SF_LOSS_WS_COUNTER_DOUBLES doubles, arrival counters that MUST BE ZERO before the first call
+ *     using this workspace; every call leaves them zero.  Calls sharing a workspace must be
+ *     ordered on one stream.
  * sf_image_station_loss_bwd -- one launch, one read of pred and target, one write of dpred.
  *   dpred f32 [B,1,H,W] = upstream * d total / d pred, complete (image term and the station
  *     windows' terms summed in registers before the one store: no atomics, bit-reproducible).
@@ -408,9 +414,10 @@ int sf_lonlat_to_pixel(const double* lon, const double* lat, int n, double lon_m
  *   fwd_losses: the losses [5] the forward call on the same inputs wrote.
  * sf_image_station_loss -- both, back to back, upstream 1: losses f32 [4] = total, image,
  *   station, 1 (dpred is already divided by the weight sum; callers that multiply dpred by
- *   losses[3] stay correct).  Its ws may hold anything (the counter is cleared on the stream).
+ *   losses[3] stay correct).  Its ws may hold anything (the counters are cleared on the stream).
  */
 #define SF_LOSS_WS_DOUBLES 4096
+#define SF_LOSS_WS_COUNTER_DOUBLES 496
 int sf_image_station_loss_fwd(const float* pred, const float* target, const int* pos,
                               const float* runoff, const int* offsets, int S, int B, int H, int W,
                               int TH, int TW, int image_metric, float nonzero_weight,

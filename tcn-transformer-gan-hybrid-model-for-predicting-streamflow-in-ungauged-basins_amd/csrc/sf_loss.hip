@@ -68,15 +68,23 @@ __device__ __forceinline__ int sample_of(const int* offsets, int B, int s) {
 // Workspace layout (doubles): per-block partial sums, written in full by every call and folded in
 // a fixed order by whichever block finishes last, so the losses are bit-reproducible; the folded
 // scalars the backward pass needs; the arrival counter (zero between calls).
-constexpr int LP = 1020;                  // max pixel blocks
-constexpr int LS = 1020;                  // max station blocks
+constexpr int LP = 896;                   // max pixel blocks
+constexpr int LS = 896;                   // max station blocks
 constexpr int WS_W = 0;                   // [LP] sum of pixel weights
 constexpr int WS_L = LP;                  // [LP] sum of weight * pixel loss
 constexpr int WS_ST = 2 * LP;             // [LS] station loss terms
 constexpr int WS_SC = 2 * LP + LS;        // [LS] stations with a non-empty window
 constexpr int WS_SCAL = 2 * LP + 2 * LS;  // two floats: 1 / sum of pixel weights, 1 / stations counted (forward + backward in one call)
-constexpr int WS_ARRIVED = SF_LOSS_WS_DOUBLES - 1;   // int: blocks that have written their partials
-static_assert(WS_SCAL < WS_ARRIVED, "loss workspace layout");
+// Arrival counters (ints, zero between calls).  A few thousand fetch-adds on ONE address take tens
+// of microseconds (they are served one after the other), so blocks arrive in groups of ARRIVE_GROUP
+// on a counter of their own 128-byte line, and only the last block of each group goes on to the
+// top counter; whoever is last there folds.  Every last arriver puts its counter back to zero.
+constexpr int ARRIVE_GROUP = 64;
+constexpr int WS_GROUPS = WS_SCAL + 16;   // group g: the int at double WS_GROUPS + 16 g
+constexpr int MAX_GROUPS = (LP + LS + ARRIVE_GROUP - 1) / ARRIVE_GROUP;
+constexpr int WS_ARRIVED = SF_LOSS_WS_DOUBLES - 1;   // top counter; the one slot a caller's workspace has to hold zero in
+static_assert(WS_GROUPS + 16 * MAX_GROUPS <= WS_ARRIVED, "loss workspace layout");
+static_assert(SF_LOSS_WS_DOUBLES - WS_GROUPS == SF_LOSS_WS_COUNTER_DOUBLES, "the counter region the header promises");
 
 __device__ __forceinline__ float pixel_weight(const LossArgs& a, float t) {
     return 1.0f + (a.nonzero_weight - 1.0f) * (fabsf(t) > a.zero_threshold ? 1.0f : 0.0f);
@@ -176,6 +184,22 @@ __device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, 
                     }
                 }
             }
+            // backward: the first 64 stations of each row's sample are requested here, beside the
+            // prediction loads, so that their two dependent round trips (offsets, then positions
+            // and differences) are over by the time the gradient is formed
+            int st_s0[2] = {0, 0}, st_s1[2] = {0, 0}, st_px[2] = {0, 0}, st_py[2] = {0, 0};
+            float st_d[2] = {0.f, 0.f};
+            if (BWD && a.S > 0 && gstn != 0.f) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int bj = __builtin_amdgcn_readfirstlane(bb[j]);
+                    st_s0[j] = a.offsets[bj]; st_s1[j] = a.offsets[bj + 1];
+                    const int s = st_s0[j] + lane;
+                    const int sc = max(s < st_s1[j] ? s : st_s1[j] - 1, 0);
+                    st_px[j] = a.pos[2 * sc]; st_py[j] = a.pos[2 * sc + 1];
+                    st_d[j] = sdiff ? sdiff[sc] : 0.f;
+                }
+            }
             if (staged) {
                 // rows ay[j].i0 / ay[j].i1 of the target -> srow[wl][2j], srow[wl][2j+1]
                 __builtin_amdgcn_wave_barrier();          // the previous pair's reads are done (same wave, in order)
@@ -236,23 +260,25 @@ __device__ __forceinline__ void pixel_pass(const LossArgs& a, int pixel_blocks, 
                 }
             }
             if (BWD) {
-                // stations of the two rows' samples, 64 at a time, one per lane: window, coefficient,
-                // then every station whose window holds one of the rows is handed round the wave
+                // every station of the rows' samples whose window holds one of the two rows is handed
+                // round the wave and added, in station order, to the pixels it covers
                 if (a.S > 0 && gstn != 0.f) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int s0 = a.offsets[bb[j]], s1 = a.offsets[bb[j] + 1];
-                        for (int base = s0; base < s1; base += 64) {
+                        for (int base = st_s0[j]; base < st_s1[j]; base += 64) {
+                            int px = st_px[j], py = st_py[j];
+                            float d = st_d[j];
                             const int s = base + lane;
-                            const int sc = s < s1 ? s : s1 - 1;
-                            const int px = a.pos[2 * sc], py = a.pos[2 * sc + 1];
+                            if (base != st_s0[j]) {                       // later chunks (more than 64 stations in the sample)
+                                const int sc = s < st_s1[j] ? s : st_s1[j] - 1;
+                                px = a.pos[2 * sc]; py = a.pos[2 * sc + 1];
+                                d = sdiff ? sdiff[sc] : 0.f;
+                            }
                             StationLane st;
                             st.y0 = max(0, py - half); st.y1 = min(a.H, py + half + 1);
                             st.x0 = max(0, px - half); st.x1 = min(a.W, px + half + 1);
                             const int n = (st.y1 > st.y0 && st.x1 > st.x0) ? (st.y1 - st.y0) * (st.x1 - st.x0) : 0;
-                            const bool hit = s < s1 && n > 0 && yy[j] >= st.y0 && yy[j] < st.y1 && 2 * pr + j < rows;
-                            float d = 0.f;
-                            if (sdiff) d = sdiff[sc];
+                            const bool hit = s < st_s1[j] && n > 0 && yy[j] >= st.y0 && yy[j] < st.y1 && 2 * pr + j < rows;
                             unsigned long long m = __ballot(hit);
                             if (!sdiff && m) {
                                 // no saved differences: the window means of the hit stations are gathered again
@@ -343,9 +369,20 @@ __global__ __launch_bounds__(NT) void loss_fwd_kernel(LossArgs a, double* __rest
     }
     // arrival: thread 0's partials are released with its ticket; the last block acquires everyone's
     if (threadIdx.x == 0) {
-        int* arrived = reinterpret_cast<int*>(ws + WS_ARRIVED);
-        const int ticket = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == (int)gridDim.x - 1;
+        const int nblk = (int)gridDim.x, grp = (int)blockIdx.x / ARRIVE_GROUP;
+        const int ngrp = (nblk + ARRIVE_GROUP - 1) / ARRIVE_GROUP;
+        const int in_grp = min(ARRIVE_GROUP, nblk - grp * ARRIVE_GROUP);
+        int* gc = reinterpret_cast<int*>(ws + WS_GROUPS + 16 * grp);
+        int last = 0;
+        if (__hip_atomic_fetch_add(gc, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+            __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int* top = reinterpret_cast<int*>(ws + WS_ARRIVED);
+            if (__hip_atomic_fetch_add(top, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) {
+                __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -362,7 +399,6 @@ __global__ __launch_bounds__(NT) void loss_fwd_kernel(LossArgs a, double* __rest
         if (scal != losses + 3) losses[3] = 1.0f;      // the caller gets the finished gradient (see loss_fused)
         scal[0] = (float)(1.0 / sw);
         scal[1] = cnt > 0.0 ? (float)(1.0 / cnt) : 0.f;
-        __hip_atomic_store(reinterpret_cast<int*>(ws + WS_ARRIVED), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -661,7 +697,7 @@ static int loss_fused(const char* who, const float* pred, const float* target, c
     int rc = loss_plan(who, q, pred, target, pos, runoff, offsets, S, B, H, W, TH, TW, image_metric, nonzero_weight,
                        zero_threshold, ksize, station_metric, image_weight, station_weight, dpred);
     if (rc != SF_OK) return rc;
-    if (zero_counter && hipMemsetAsync(ws + WS_ARRIVED, 0, sizeof(double), s) != hipSuccess) {
+    if (zero_counter && hipMemsetAsync(ws + WS_GROUPS, 0, sizeof(double) * (SF_LOSS_WS_DOUBLES - WS_GROUPS), s) != hipSuccess) {
         sf_set_error("%s: clearing the workspace counter failed", who);
         return SF_ELAUNCH;
     }

@@ -69,7 +69,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nchw_to_nhwc_checked", "sf_nchw_bf16_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
+EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_tile_shape", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nchw_to_nhwc_checked", "sf_nchw_bf16_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_bn_relu_avgpool_fwd_moments", "sf_bn_bwd_reduce_pooled", "sf_channel_sum", "sf_colsum_f32",
            "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",

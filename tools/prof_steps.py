@@ -1,5 +1,5 @@
 """Per-kernel time per train step from a rocprofv3 kernel trace, restricted to the timed loop (the
-longest run of steps, marked by loss_main_kernel, less than 25 ms apart).
+longest run of steps, marked by the loss's forward kernel, less than 25 ms apart).
     python tools/prof_steps.py x.db [steps] [out.csv]"""
 import collections
 import csv
@@ -12,7 +12,7 @@ def window_rows(path, steps):
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name = "name" if "name" in cols else "kernel_name"
     rows = sorted(cur.execute(f"select start, end, {name} from kernels").fetchall())
-    marks = [r[0] for r in rows if "loss_main_kernel" in r[2]]
+    marks = [r[0] for r in rows if "loss_fwd_kernel" in r[2] or "loss_main_kernel" in r[2]]     # one per train step
     runs, run = [], [marks[0]]
     for a, b in zip(marks, marks[1:]):
         if b - a < 25e6:

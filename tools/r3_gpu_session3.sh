@@ -1,0 +1,26 @@
+#!/bin/bash
+# GPU tests, then an A/B of the tile rule on one box (legacy "fewest tiles" against the conflict-aware
+# rule), then a kernel trace of the default.
+export TMPDIR=/tmp
+TAG=${1:-r3c}
+mkdir -p gpurun_out
+timeout -k 10 1000 python -u -m pytest tests -m gpu -q --timeout 300 --timeout-method thread -p no:cacheprovider > gpurun_out/${TAG}_tests.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/${TAG}_tests.log
+grep -E "^(FAILED|ERROR)|passed|failed|rc=|least aligned|largest bf16" gpurun_out/${TAG}_tests.log | tail -n 25
+for i in 1 2; do
+  SF_CONV3_TILE=fewest timeout -k 10 200 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_old$i.log 2>/dev/null || { echo "bench old failed"; exit 1; }
+  timeout -k 10 200 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_new$i.log 2>/dev/null || { echo "bench new failed"; exit 1; }
+done
+python - <<'PY'
+import json, glob, os
+tag = os.environ.get("TAG", "r3c")
+for f in sorted(glob.glob("gpurun_out/*_bench_*.log")):
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print(os.path.basename(f), d["ms_per_step"], "wide", r["ms_per_launch"], {k: v["ms_per_launch"] for k, v in r["other"].items()})
+PY
+timeout -s KILL 240 rocprofv3 --kernel-trace -d gpurun_out/${TAG}_trace -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_trace.log 2>&1 || { echo "trace failed"; tail -n 5 gpurun_out/${TAG}_trace.log; exit 1; }
+python tools/prof_steps.py $(ls -t gpurun_out/${TAG}_trace/*/*.db | head -n 1) 36 gpurun_out/${TAG}_kernel_stats.csv > gpurun_out/${TAG}_steps.txt 2>&1
+head -n 14 gpurun_out/${TAG}_steps.txt
+grep -E "loss_|nan_inf" gpurun_out/${TAG}_steps.txt
+rm -rf gpurun_out/${TAG}_trace
