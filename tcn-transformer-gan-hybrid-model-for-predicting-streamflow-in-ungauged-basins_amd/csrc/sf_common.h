@@ -4,7 +4,12 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <map>
 #include <mutex>
+#include <stdlib.h>
+#include <string.h>
+#include <utility>
+#include <vector>
 
 typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -211,3 +216,108 @@ struct StreamSlots {
         return n++;
     }
 };
+
+// ---- tile shapes of the persistent LDS-DMA conv kernels -----------------------------------------
+// LDS cycles of the patch-fragment reads (ds_read_b128) of a TH x TW pixel tile, averaged over the
+// waves, pixel groups and taps of an item.  The patch is an array of `rowb`-byte rows, one per patch
+// pixel, (TW + halo) pixels wide; lane r of a group of 32 consecutive tile pixels reads the row of
+// its pixel shifted by the tap, 16-byte slot XORed with (row >> 3) & 1 (32-byte rows) or
+// (row >> 2) & 3 (64-byte rows).  The hardware serves a wave's read in four fixed groups of 16
+// lanes, one cycle per group when the lanes touch 16 different slots of the 256-byte bank window
+// and one more for every further distinct address on a slot.  32 consecutive pixels of one tile row
+// are conflict-free by construction of the swizzle; every wrap to the next tile row inside a group
+// shifts the later lanes by `halo` rows and costs cycles, so the tile width decides how often that
+// happens (4.0 = never).
+inline double lds_patch_read_cycles(int TW, int TH, int halo, int rowb, int row0, const int* tap_dy, const int* tap_dx,
+                                    int ntaps) {
+    static const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const int PW = TW + halo, TP = TH * TW, ks_n = rowb / 32;
+    long long total = 0, reads = 0;
+    for (int wave = 0; wave < 8; ++wave)
+        for (int c = 0; c < 2; ++c)
+            for (int t = 0; t < ntaps; ++t)
+                for (int ks = 0; ks < ks_n; ++ks) {
+                    int addr[32];
+                    for (int r = 0; r < 32; ++r) {
+                        int q = wave * 64 + c * 32 + r;
+                        if (q >= TP) q = 0;
+                        const int ly = q / TW, lx = q - ly * TW;
+                        const int row = row0 + (ly + tap_dy[t]) * PW + lx + tap_dx[t];
+                        const int sw = rowb == 64 ? (row >> 2) & 3 : (row >> 3) & 1;
+                        addr[r] = (row * rowb + (sw << 4)) ^ (ks << 5);        // h = 0; h = 1 is the same pattern one slot on
+                    }
+                    for (int g = 0; g < 2; ++g) {
+                        int slot_addr[16][16], slot_n[16] = {0};
+                        int worst = 1;
+                        for (int i = 0; i < 16; ++i) {
+                            const int ai = addr[groups[g][i]], sl = (ai >> 4) & 15;
+                            bool seen = false;
+                            for (int k = 0; k < slot_n[sl]; ++k) seen |= slot_addr[sl][k] == ai;
+                            if (!seen) slot_addr[sl][slot_n[sl]++] = ai;
+                            if (slot_n[sl] > worst) worst = slot_n[sl];
+                        }
+                        total += 2 * worst;      // both halves of the wave (h = 0 and h = 1)
+                    }
+                    ++reads;
+                }
+    return (double)total / (double)reads;
+}
+
+// Tile of at most tp_max pixels whose (TH + halo) x (TW + halo) patch fits pp_max rows.  Among the
+// shapes within 3 % of the fewest tiles the one whose patch reads cost the fewest LDS cycles is
+// taken (then fewer tiles, then the smaller patch).  Environment variable `env` (experiments):
+// "TWxTH" forces a shape, "fewest" restores the plain fewest-tiles / least-halo rule.  The choice is
+// remembered per (memo key, image size, row width).
+struct TileChoice { int th, tw; double cycles; };
+inline TileChoice pick_tile_lds(int kind, int H, int W, int tp_max, int pp_max, int halo, int rowb, int row0_scale,
+                                const int* tap_dy, const int* tap_dx, int ntaps, const char* env) {
+    static std::mutex mu;
+    static std::map<long long, TileChoice> memo;
+    const long long key = ((long long)kind << 60) | ((long long)H << 36) | ((long long)W << 8) | rowb;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+    }
+    // row0 = row0_scale * (PW + 1): the patch row of tile pixel (0, 0) (1 halo row and column in front for the 3x3 taps)
+    auto cycles_of = [&](int tw, int th) {
+        return lds_patch_read_cycles(tw, th, halo, rowb, row0_scale * (tw + halo + 1), tap_dy, tap_dx, ntaps);
+    };
+    int fth = 0, ftw = 0;
+    bool legacy = false;
+    if (const char* force = getenv(env)) {
+        legacy = strcmp(force, "fewest") == 0;
+        if (sscanf(force, "%dx%d", &ftw, &fth) != 2 || ftw < 4 || fth < 1 || fth * ftw > tp_max ||
+            (fth + halo) * (ftw + halo) > pp_max)
+            fth = ftw = 0;
+    }
+    struct Cand { int th, tw, pp; long long tiles; };
+    std::vector<Cand> cands;
+    long long fewest = -1;
+    for (int w = 4; w <= tp_max; ++w) {
+        int hh = tp_max / w;
+        if (hh > H) hh = H;
+        if (hh < 1) continue;
+        const int pp = (hh + halo) * (w + halo);
+        if (pp > pp_max) continue;
+        const long long tiles = (long long)((W + w - 1) / w) * ((H + hh - 1) / hh);
+        cands.push_back({hh, w, pp, tiles});
+        if (fewest < 0 || tiles < fewest) fewest = tiles;
+    }
+    TileChoice best{1, 8, 0.0};
+    int bpp = 0;
+    long long btiles = -1;
+    for (const Cand& c : cands) {
+        if (c.tiles * 100 > fewest * 103) continue;
+        const double cyc = legacy ? 0.0 : cycles_of(c.tw, c.th);
+        const bool better = btiles < 0 || cyc < best.cycles - 1e-9 ||
+                            (cyc < best.cycles + 1e-9 && (c.tiles < btiles || (c.tiles == btiles && c.pp < bpp)));
+        if (better) { btiles = c.tiles; best = {c.th, c.tw, cyc}; bpp = c.pp; }
+    }
+    if (fth) best = {fth, ftw, 0.0};
+    best.cycles = cycles_of(best.tw, best.th);
+    std::lock_guard<std::mutex> lock(mu);
+    memo[key] = best;
+    return best;
+}

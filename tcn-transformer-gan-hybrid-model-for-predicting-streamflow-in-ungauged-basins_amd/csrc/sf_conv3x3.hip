@@ -13,10 +13,6 @@
 #include "sf_common.h"
 #include "../../include/sfhip.h"
 #include <atomic>
-#include <map>
-#include <stdlib.h>
-#include <string.h>
-#include <vector>
 
 namespace {
 
@@ -829,94 +825,11 @@ __global__ __launch_bounds__(D_NT, 2) void conv3_dma_res_mask_kernel(C3DParams p
 __global__ __launch_bounds__(D_NT, 2) void conv3_dma_wide_any_kernel(C3DParams p) { conv3_dma_body<128, 16, false, 0>(p); }
 __global__ __launch_bounds__(D_NT, 2) void conv3_dma_wide_kernel(C3DParams p) { conv3_dma_body<128, 16, false, 1>(p); }
 
-// LDS cycles of the patch-fragment reads (ds_read_b128) of a tile shape, averaged over the waves,
-// pixel groups and taps of an item, for rows of `rowb` bytes: the hardware serves a wave's read in
-// four fixed groups of 16 lanes, one cycle per group when the 16 lanes touch 16 different 16-byte
-// slots of the 256-byte bank window and one more for every further distinct address on a slot.
-// 32 consecutive pixels of one tile row are conflict-free by construction of the slot swizzle; every
-// wrap to the next tile row inside a group of 32 pixels shifts the later lanes by the two halo
-// columns and costs cycles, so the tile width decides how often that happens (4.0 = none).
-double patch_read_cycles(int TW, int TH, int rowb) {
-    static const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
-                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
-    const int PW = TW + 2, TP = TH * TW, ks_n = rowb / 32;
-    long long total = 0, reads = 0;
-    for (int wave = 0; wave < 8; ++wave)
-        for (int c = 0; c < 2; ++c)
-            for (int t = 0; t < 9; ++t)
-                for (int ks = 0; ks < ks_n; ++ks) {
-                    int addr[32];
-                    for (int r = 0; r < 32; ++r) {
-                        int q = wave * 64 + c * 32 + r;
-                        if (q >= TP) q = 0;
-                        const int ly = q / TW, lx = q - ly * TW;
-                        const int row = (ly + 1) * PW + lx + 1 + (t / 3 - 1) * PW + (t % 3 - 1);
-                        const int sw = rowb == 64 ? (row >> 2) & 3 : (row >> 3) & 1;
-                        addr[r] = (row * rowb + (sw << 4)) ^ (ks << 5);        // h = 0; h = 1 is the same pattern one slot on
-                    }
-                    for (int g = 0; g < 2; ++g) {
-                        int slot_addr[16][16], slot_n[16] = {0};
-                        int worst = 1;
-                        for (int i = 0; i < 16; ++i) {
-                            const int ai = addr[groups[g][i]], sl = (ai >> 4) & 15;
-                            bool seen = false;
-                            for (int k = 0; k < slot_n[sl]; ++k) seen |= slot_addr[sl][k] == ai;
-                            if (!seen) slot_addr[sl][slot_n[sl]++] = ai;
-                            if (slot_n[sl] > worst) worst = slot_n[sl];
-                        }
-                        total += 2 * worst;      // both halves of the wave (h = 0 and h = 1)
-                    }
-                    ++reads;
-                }
-    return (double)total / (double)reads;
-}
-
-// Tile of the persistent kernel: at most D_TP pixels, patch at most D_PP.  Among the shapes within
-// 3 % of the fewest tiles the one whose patch reads cost the fewest LDS cycles is taken (then fewer
-// tiles, then the smaller halo).  The choice is remembered per image size and row width.
-void pick_tile_dma(int H, int W, int rowb, int* th, int* tw) {
-    static std::mutex mu;
-    static std::map<long long, std::pair<int, int>> memo;
-    const long long key = ((long long)H << 36) | ((long long)W << 8) | rowb;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        auto it = memo.find(key);
-        if (it != memo.end()) { *th = it->second.first; *tw = it->second.second; return; }
-    }
-    int fth = 0, ftw = 0;
-    bool legacy = false;
-    if (const char* force = getenv("SF_CONV3_TILE")) {        // experiments: "TWxTH", or "fewest" = fewest tiles, least halo
-        legacy = strcmp(force, "fewest") == 0;
-        if (sscanf(force, "%dx%d", &ftw, &fth) != 2 || ftw < 4 || fth < 1 || fth * ftw > D_TP || (fth + 2) * (ftw + 2) > D_PP)
-            fth = ftw = 0;
-    }
-    struct Cand { int th, tw, pp; long long tiles; };
-    std::vector<Cand> cands;
-    long long fewest = -1;
-    for (int w = 4; w <= D_TP; ++w) {
-        int hh = D_TP / w;
-        if (hh > H) hh = H;
-        if (hh < 1) continue;
-        const int pp = (hh + 2) * (w + 2);
-        if (pp > D_PP) continue;
-        const long long tiles = (long long)((W + w - 1) / w) * ((H + hh - 1) / hh);
-        cands.push_back({hh, w, pp, tiles});
-        if (fewest < 0 || tiles < fewest) fewest = tiles;
-    }
-    int bth = 1, btw = 8, bpp = 0;
-    long long btiles = -1;
-    double bcyc = 0.0;
-    for (const Cand& c : cands) {
-        if (c.tiles * 100 > fewest * 103) continue;
-        const double cyc = legacy ? (double)c.tiles : patch_read_cycles(c.tw, c.th, rowb);
-        const bool better = btiles < 0 || cyc < bcyc - 1e-9 ||
-                            (cyc < bcyc + 1e-9 && (c.tiles < btiles || (c.tiles == btiles && c.pp < bpp)));
-        if (better) { btiles = c.tiles; bth = c.th; btw = c.tw; bpp = c.pp; bcyc = cyc; }
-    }
-    if (fth) { bth = fth; btw = ftw; }
-    *th = bth; *tw = btw;
-    std::lock_guard<std::mutex> lock(mu);
-    memo[key] = {bth, btw};
+// tile of the persistent kernel: at most D_TP pixels, patch at most D_PP rows (pick_tile_lds: fewest
+// tiles within 3 %, then the fewest LDS cycles of the patch-fragment reads)
+TileChoice pick_tile_dma(int H, int W, int rowb) {
+    static const int dy[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, dx[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
+    return pick_tile_lds(0, H, W, D_TP, D_PP, 2, rowb, 1, dy, dx, 9, "SF_CONV3_TILE");
 }
 
 template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, hipStream_t s) {
@@ -927,7 +840,7 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
     p.act = q.act; p.aux_mode = q.aux_mode; p.out_dtype = q.out_dtype; p.wstaged = q.wstaged;
     p.dot_w = q.dot_w; p.dot_b = q.dot_b; p.dot_out = q.dot_out;
     for (int t = 0; t < 9; ++t) { p.dy[t] = q.dy[t]; p.dx[t] = q.dx[t]; }
-    pick_tile_dma(p.H, p.W, Cf::ROWB, &p.TH, &p.TW);
+    { const TileChoice tc = pick_tile_dma(p.H, p.W, Cf::ROWB); p.TH = tc.th; p.TW = tc.tw; }
     p.tiles_x = (p.W + p.TW - 1) / p.TW;
     p.tiles_y = (p.H + p.TH - 1) / p.TH;
     const long long ntiles = (long long)p.N * p.tiles_x * p.tiles_y;
@@ -1069,8 +982,9 @@ extern "C" int sf_conv3x3(const void* in, const void* wp, const float* bias, con
 
 extern "C" int sf_conv3x3_tile_shape(int H, int W, int row_bytes, int* th, int* tw, double* read_cycles) {
     SF_REQUIRE(H > 0 && W > 0 && (row_bytes == 32 || row_bytes == 64) && th && tw, "sf_conv3x3_tile_shape: bad arguments");
-    pick_tile_dma(H, W, row_bytes, th, tw);
-    if (read_cycles) *read_cycles = patch_read_cycles(*tw, *th, row_bytes);
+    const TileChoice tc = pick_tile_dma(H, W, row_bytes);
+    *th = tc.th; *tw = tc.tw;
+    if (read_cycles) *read_cycles = tc.cycles;
     return SF_OK;
 }
 

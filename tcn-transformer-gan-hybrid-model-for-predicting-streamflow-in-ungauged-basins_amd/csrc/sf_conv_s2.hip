@@ -386,20 +386,12 @@ __global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_mask64_kernel(S2Params 
 __global__ __launch_bounds__(S_NT, 2) void conv_s2_dgrad_any64_kernel(S2Params p) { conv_s2_body<true, 0, 2>(p); }
 __global__ __launch_bounds__(S_NT, 2) void conv_s2_fwd_any64_kernel(S2Params p) { conv_s2_body<false, 0, 2>(p); }
 
-// tile of at most S_TP pixels whose (TH+1) x (TW+1) patch fits S_PP rows: fewest tiles, least halo
+// tile of at most S_TP pixels whose (TH+1) x (TW+1) patch fits S_PP rows (pick_tile_lds: fewest tiles
+// within 3 %, then the fewest LDS cycles of the patch-fragment reads)
 void pick_tile_s2(int H, int W, int* th, int* tw) {
-    long long best = -1;
-    int bth = 1, btw = 8, bpp = 0;
-    for (int w = 4; w <= S_TP; ++w) {
-        int hh = S_TP / w;
-        if (hh > H) hh = H;
-        if (hh < 1) continue;
-        const int pp = (hh + 1) * (w + 1);
-        if (pp > S_PP) continue;
-        const long long tiles = (long long)((W + w - 1) / w) * ((H + hh - 1) / hh);
-        if (best < 0 || tiles < best || (tiles == best && pp < bpp)) { best = tiles; bth = hh; btw = w; bpp = pp; }
-    }
-    *th = bth; *tw = btw;
+    static const int dy[4] = {0, 0, 1, 1}, dx[4] = {0, 1, 0, 1};
+    const TileChoice tc = pick_tile_lds(1, H, W, S_TP, S_PP, 1, ROWB, 0, dy, dx, 4, "SF_CONV_S2_TILE");
+    *th = tc.th; *tw = tc.tw;
 }
 
 // packed [K][16][C] weights (tap index class * 4 + a * 2 + b) -> the LDS images of the stages, one

@@ -90,6 +90,10 @@ __device__ __forceinline__ float pixel_weight(const LossArgs& a, float t) {
     return 1.0f + (a.nonzero_weight - 1.0f) * (fabsf(t) > a.zero_threshold ? 1.0f : 0.0f);
 }
 
+// a partial sum on its way to another workgroup of the same launch: written through at agent scope
+__device__ __forceinline__ void publish(double* slot, double v) {
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // sum of n partials (n <= 1024) by one 256-thread block, fixed order; valid in every thread.  The
 // partials were written by other workgroups of the same launch: they are read at agent scope.
 __device__ __forceinline__ double fold_partials(const double* part, int n, double* sm) {
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(NT) void loss_fwd_kernel(LossArgs a, double* __rest
         pixel_pass<V, false>(a, pixel_blocks, 0.f, 0.f, nullptr, nullptr, accw, accl, bad);
         const double sw = block_sum_256_d((double)accw, smd);
         const double sl = block_sum_256_d((double)accl, smd);
-        if (threadIdx.x == 0) { ws[WS_W + blockIdx.x] = sw; ws[WS_L + blockIdx.x] = sl; }
+        if (threadIdx.x == 0) { publish(ws + WS_W + blockIdx.x, sw); publish(ws + WS_L + blockIdx.x, sl); }
         if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
     } else {
         const int sb = (int)blockIdx.x - pixel_blocks;
@@ -365,19 +369,23 @@ __global__ __launch_bounds__(NT) void loss_fwd_kernel(LossArgs a, double* __rest
         }
         tl = block_sum_256_d(tl, smd);
         tc = block_sum_256_d(tc, smd);
-        if (threadIdx.x == 0) { ws[WS_ST + sb] = tl; ws[WS_SC + sb] = tc; }
+        if (threadIdx.x == 0) { publish(ws + WS_ST + sb, tl); publish(ws + WS_SC + sb, tc); }
     }
-    // arrival: thread 0's partials are released with its ticket; the last block acquires everyone's
+    // Arrival.  The partials were written through to device-coherent memory (publish) and are read
+    // back the same way (fold_partials), so the hand-over needs no release / acquire fence -- an
+    // agent-scope release would write back this XCD's whole L2, once per block: the counters are
+    // plain relaxed fetch-adds behind a drain of thread 0's own stores.
     if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int nblk = (int)gridDim.x, grp = (int)blockIdx.x / ARRIVE_GROUP;
         const int ngrp = (nblk + ARRIVE_GROUP - 1) / ARRIVE_GROUP;
         const int in_grp = min(ARRIVE_GROUP, nblk - grp * ARRIVE_GROUP);
         int* gc = reinterpret_cast<int*>(ws + WS_GROUPS + 16 * grp);
         int last = 0;
-        if (__hip_atomic_fetch_add(gc, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+        if (__hip_atomic_fetch_add(gc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
             __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int* top = reinterpret_cast<int*>(ws + WS_ARRIVED);
-            if (__hip_atomic_fetch_add(top, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) {
+            if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) {
                 __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 last = 1;
             }
