@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "tcn-transformer-gan-hybrid-model-for-predicting-streamflow-in-ungauged-basins_amd"
 
-PMC_TRAFFIC = "r2_pmc_hbm_traffic.json"
+PMC_TRAFFIC = "r3_pmc_hbm_traffic.json"
 PMC_MFMA = "r3_pmc_mfma.json"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (spec)
 REPEATS = 3                     # the timed block of K steps is run this many times; the median is reported

@@ -83,6 +83,7 @@ constexpr int ARRIVE_GROUP = 64;
 constexpr int WS_GROUPS = WS_SCAL + 16;   // group g: the int at double WS_GROUPS + 16 g
 constexpr int MAX_GROUPS = (LP + LS + ARRIVE_GROUP - 1) / ARRIVE_GROUP;
 constexpr int WS_ARRIVED = SF_LOSS_WS_DOUBLES - 1;   // top counter; the one slot a caller's workspace has to hold zero in
+static_assert(LS == LP, "the fold walks both kinds of partials with one index");
 static_assert(WS_GROUPS + 16 * MAX_GROUPS <= WS_ARRIVED, "loss workspace layout");
 static_assert(SF_LOSS_WS_DOUBLES - WS_GROUPS == SF_LOSS_WS_COUNTER_DOUBLES, "the counter region the header promises");
 
@@ -94,14 +95,6 @@ __device__ __forceinline__ float pixel_weight(const LossArgs& a, float t) {
 __device__ __forceinline__ void publish(double* slot, double v) {
     __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// sum of n partials (n <= 1024) by one 256-thread block, fixed order; valid in every thread.  The
-// partials were written by other workgroups of the same launch: they are read at agent scope.
-__device__ __forceinline__ double fold_partials(const double* part, int n, double* sm) {
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += NT) v += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return block_sum_256_d(v, sm);
-}
-
 // The pixel passes walk the prediction grid by rows: a wave takes pairs of adjacent rows (b, y),
 // pair = wave, wave + nwaves, ... and its lanes take V consecutive pixels each of up to two column
 // groups, so the horizontal resize taps of a lane are computed once and kept for all its rows, the
@@ -394,10 +387,28 @@ __global__ __launch_bounds__(NT) void loss_fwd_kernel(LossArgs a, double* __rest
     }
     __syncthreads();
     if (!s_last) return;
-    const double cnt = fold_partials(ws + WS_SC, station_blocks, smd);
-    const double sw = fold_partials(ws + WS_W, pixel_blocks, smd);
-    const double sl = fold_partials(ws + WS_L, pixel_blocks, smd);
-    const double tl = fold_partials(ws + WS_ST, station_blocks, smd);
+    // all four partial arrays at once (their loads are independent: one round trip, not four), each
+    // summed in a fixed order: thread t takes slots t, t + 256, ..., then the waves, then the block
+    __shared__ double sfold[4][NT / 64];
+    double f[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < LP; i += NT) {
+        const bool ip = i < pixel_blocks, is = i < station_blocks;
+        const double a0 = __hip_atomic_load(ws + WS_SC + (is ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double a1 = __hip_atomic_load(ws + WS_W + (ip ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double a2 = __hip_atomic_load(ws + WS_L + (ip ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double a3 = __hip_atomic_load(ws + WS_ST + (is ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f[0] += is ? a0 : 0.0; f[1] += ip ? a1 : 0.0; f[2] += ip ? a2 : 0.0; f[3] += is ? a3 : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f[q] = wave_sum_d(f[q]);
+        if ((threadIdx.x & 63) == 0) sfold[q][threadIdx.x >> 6] = f[q];
+    }
+    __syncthreads();
+    const double cnt = sfold[0][0] + sfold[0][1] + sfold[0][2] + sfold[0][3];
+    const double sw = sfold[1][0] + sfold[1][1] + sfold[1][2] + sfold[1][3];
+    const double sl = sfold[2][0] + sfold[2][1] + sfold[2][2] + sfold[2][3];
+    const double tl = sfold[3][0] + sfold[3][1] + sfold[3][2] + sfold[3][3];
     if (threadIdx.x == 0) {
         const float img = (float)(sl / sw);
         const float stn = cnt > 0.0 ? (float)(tl / cnt) : 0.f;
