@@ -267,21 +267,30 @@ int sf_channel_sum(const void* x, int dtype, long long M, int C, int Creal, floa
  * recomputed in each pass and never stored:
  *   sf_enc1_stats: ws[0..K) = sum, ws[K..2K) = sum of squares of the bf16-rounded conv output
  *                  (ws zeroed here; feed sf_bn_finalize with M = N*H*W)
- *   sf_enc1_fwd:   y[N,H/2,W/2,K] = maxpool2x2(relu(conv*scale + shift)) */
+ *   sf_enc1_fwd:   y[N,H/2,W/2,K] = maxpool2x2(relu(conv*scale + shift)); when `codes` is not
+ *                  NULL (sf_enc1_codes_bytes bytes) it also leaves, per pooling window and
+ *                  channel, which of the four positions held the maximum (the first on ties,
+ *                  as torch's max-pool backward picks it) and whether it passed the ReLU */
 int sf_enc1_stats(const void* x, const void* w, double* ws, int N, int H, int W, int K, void* stream);
+size_t sf_enc1_codes_bytes(int N, int H, int W, int K);
 int sf_enc1_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y,
-                int N, int H, int W, int K, void* stream);
+                void* codes, int N, int H, int W, int K, void* stream);
 /*   sf_enc1_bwd:   from dy (gradient wrt the pooled map, NHWC bf16 [N,H/2,W/2,K]) the gradients
  *                  dw f32 [K,Creal,3,3], dgamma, dbeta f32 [K] of conv weight and BatchNorm
  *                  (training != 0: batch statistics took part in the forward); the input gets
- *                  no gradient.  Creal <= 14 real input channels; ws: workspace of
+ *                  no gradient.  Creal <= 14 real input channels; ws: 8-byte aligned workspace of
  *                  sf_enc1_bwd_workspace_bytes bytes (per-workgroup partial results, summed in
- *                  a fixed order: reproducible). */
+ *                  a fixed order: reproducible).  codes: what sf_enc1_fwd left for the same x, w,
+ *                  scale and shift, or NULL.  With codes (and Creal <= 10) the pooled gradient is
+ *                  routed by them and everything that involves the conv output comes from two
+ *                  channel-independent sums (the correlation of the routed gradient with the
+ *                  input patches, and the patches' Gram matrix), so neither the conv nor the
+ *                  arg-max is computed again; without, both are recomputed from x. */
 size_t sf_enc1_bwd_workspace_bytes(int N, int H, int W, int K, int Creal);
-int sf_enc1_bwd(const void* x, const void* w, const void* dy, const float* scale, const float* shift,
-                const float* mean, const float* invstd, int training, float* dw, float* dgamma,
-                float* dbeta, float* ws, size_t ws_bytes, int N, int H, int W, int K, int Creal,
-                void* stream);
+int sf_enc1_bwd(const void* x, const void* w, const void* dy, const void* codes, const float* scale,
+                const float* shift, const float* mean, const float* invstd, int training, float* dw,
+                float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int N, int H, int W, int K,
+                int Creal, void* stream);
 
 /* ---- bilinear resize, align_corners=False (src/model/decoder.py:165-170, src/loss.py:49-54) */
 /* src NHWC f32 [B,h,w,C] -> dst NHWC (dtype) [B,OH,OW,C]; C == Cpad */

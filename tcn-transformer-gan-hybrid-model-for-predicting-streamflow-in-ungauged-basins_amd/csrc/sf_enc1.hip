@@ -40,7 +40,19 @@ struct E1Params {
     const float* scale;  // fwd
     const float* shift;
     bf16* y;             // fwd: [N,H/2,W/2,K]
+    unsigned short* codes;   // fwd, optional: the routing of every pooling window (layout: code_index)
 };
+
+// Routing codes.  For every pooling window and channel the forward pass can leave 3 bits: the
+// position of the window's maximum (0..3 = (0,0), (0,1), (1,0), (1,1); the first one in that order
+// on ties, as torch's max-pool backward picks it) and whether it passed the ReLU.  A lane of the
+// forward kernel owns one channel and, per window row of a tile, the four windows 2 g + h of the
+// tile's eight: their codes are packed into one 16-bit word (code g in bits 3 g .. 3 g + 2), stored
+// at [(n, pooled row wy)][tile column][h][channel].  The backward pass then routes the pooled
+// gradient with a few bit operations instead of recomputing conv + BatchNorm + arg-max.
+__host__ __device__ inline size_t code_index(int n, int wy, int tx, int h, int k, int PH, int tiles_x, int K) {
+    return ((((size_t)n * PH + wy) * tiles_x + tx) * 2 + h) * K + k;
+}
 
 __device__ __forceinline__ bf16x8 to_bf16x8(const float* f) {
     bf16x8 v;
@@ -185,16 +197,25 @@ __global__ __launch_bounds__(E_NT, 3) void enc1_kernel(E1Params p) {
                 } else {
                     const int wy = (cur.y0 >> 1) + rt;
                     bf16* yrow = p.y + (((size_t)cur.n * PH + wy) * PWd + (cur.x0 >> 1) + h) * p.K + kt * 32 + r;
+                    unsigned cw = 0;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const unsigned p01 = pack_bf16x2(acc[4 * g], acc[4 * g + 1]), p23 = pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]);
                         const float v0 = __uint_as_float(p01 << 16) * sc[kt] + sf[kt], v1 = __uint_as_float(p01 & 0xffff0000u) * sc[kt] + sf[kt];
                         const float v2 = __uint_as_float(p23 << 16) * sc[kt] + sf[kt], v3 = __uint_as_float(p23 & 0xffff0000u) * sc[kt] + sf[kt];
-                        float mx = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), 0.f);   // ReLU, then max
+                        // first maximum in the order 0,1,2,3 (strict >), as a two-level tournament
+                        const bool c1 = v1 > v0, c3 = v3 > v2;
+                        const float b01 = c1 ? v1 : v0, b23 = c3 ? v3 : v2;
+                        const bool cf = b23 > b01;
+                        const float best = cf ? b23 : b01;
+                        float mx = fmaxf(best, 0.f);                                  // ReLU of the maximum
                         if ((v0 != v0) | (v1 != v1) | (v2 != v2) | (v3 != v3)) mx = __builtin_nanf("");   // torch keeps a NaN
+                        cw |= ((cf ? 2u + (c3 ? 1u : 0u) : (c1 ? 1u : 0u)) | (best > 0.f ? 4u : 0u)) << (3 * g);
                         const int wx = (cur.x0 >> 1) + 2 * g + h;
                         if (full || (wy < PH && wx < PWd)) yrow[(size_t)2 * g * p.K] = (bf16)mx;
                     }
+                    if (p.codes && (full || wy < PH))
+                        p.codes[code_index(cur.n, wy, cur.x0 / E_TW, h, kt * 32 + r, PH, p.tiles_x, p.K)] = (unsigned short)cw;
                 }
             };
 #pragma unroll
@@ -455,6 +476,246 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd_kernel(E1Bwd a) {
     }
 }
 
+// ---- backward, routed by the forward pass's codes ------------------------------------------------
+// With the routing codes of the forward pass (code_index) the backward needs neither the conv nor
+// BatchNorm nor the arg-max again, and not the pre-activation z either: both z-dependent sums are
+// linear in quantities that do not involve the output channel,
+//     sum_p dzm[p][k] z[p][k]      = sum_col W[k][col] A1[k][col]          (A1 = dzm^T xp)
+//     A2[k][col] = sum_p z[p][k] xp[p][col] = sum_col' W[k][col'] G[col'][col]   (G = xp^T xp, the Gram
+//                                                                          matrix of the input patches)
+// so the kernel accumulates A1 (per channel tile), sum dzm and -- once, not per channel -- G; the
+// finalize kernel applies the weights.  The B operand xp[pixel][(tap, c)] of all these products is
+// the same for every channel tile: the four waves of a workgroup gather it ONCE per tile into LDS
+// as ready-made MFMA fragments (48 x 1 KiB for three column tiles) and read it back with one
+// 16-byte load per MFMA, instead of 8 two-byte gathers per MFMA and wave.
+struct E1Bwd2 {
+    E1Params c;
+    const bf16* dy;                 // [N,H/2,W/2,K] gradient wrt the pooled map
+    const unsigned short* codes;    // routing codes of the forward pass
+    float* slab;                    // [gridDim.y][gridDim.x][slab2_floats]: A1 [128][NCT*32], sum dzm [128]
+    float* gslab;                   // [gridDim.x][NP][32][32] partial Gram matrices (channel group 0 only)
+    int Creal, ncols, gram;
+};
+__host__ __device__ inline size_t slab2_floats(int nct) { return (size_t)128 * nct * 32 + 128; }
+__host__ __device__ inline int gram_pairs(int nct) { return nct * (nct + 1) / 2; }
+__host__ __device__ inline int gram_pair(int a, int b, int nct) { return a * nct - a * (a - 1) / 2 + (b - a); }   // a <= b
+
+template <int NCT>
+__global__ __launch_bounds__(E_NT, 2) void enc1_bwd2_kernel(E1Bwd2 a) {
+    constexpr int NP = NCT * (NCT + 1) / 2, NF = 16 * NCT;        // column-tile pairs; fragments per tile
+    const E1Params& p = a.c;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sP = smem;                                   // halo patch [E_PP][16 channels]
+    char* sD = sP + E_PP * E_ROWB;                     // pooled gradients [64 windows][128 channels] bf16
+    char* sC = sD + E_DCH * 16;                        // codes [8 window rows][2][128 channels] u16
+    char* sX = sC + 8 * 2 * 128 * 2;                   // fragments [16 steps][NCT][64 lanes][16 bytes]
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kt = blockIdx.y * 4 + wave;
+    const bool active = kt * 32 < p.K;
+    const bool gram = a.gram && blockIdx.y == 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (unsigned)((size_t)p.N * p.H * p.W * E_ROWB), 0x00020000);
+    const int PH = p.H / 2, PWd = p.W / 2;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (unsigned)((size_t)p.N * PH * PWd * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.codes, 0, (unsigned)((size_t)p.N * PH * p.tiles_x * 2 * p.K * 2), 0x00020000);
+    auto load_dyt = [&](const TilePos& tq, bool live, uint4* regs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < E_DLOADS; ++j) {
+            const int c = threadIdx.x + j * E_NT;
+            const int win = c >> 4, part = c & 15;
+            const int wy = (tq.y0 >> 1) + (win >> 3), wx = (tq.x0 >> 1) + (win & 7);
+            const bool ok = live && wy < PH && wx < PWd && blockIdx.y * 128 + part * 8 < p.K;
+            const int off = ok ? (((tq.n * PH + wy) * PWd + wx) * p.K + blockIdx.y * 128 + part * 8) * 2 : (int)0x80000000;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
+            regs[j] = *reinterpret_cast<const uint4*>(&v);
+        }
+    };
+    // the tile's codes: 8 window rows x 2 window parities x 128 channels, one 16-byte chunk per thread
+    auto load_codes = [&](const TilePos& tq, bool live) __attribute__((always_inline)) {
+        const int c = threadIdx.x, rt = c >> 5, hh = (c >> 4) & 1, part = c & 15;
+        const int wy = (tq.y0 >> 1) + rt, kk = blockIdx.y * 128 + part * 8;
+        const bool ok = live && wy < PH && kk < p.K;
+        const int off = ok ? (int)(code_index(tq.n, wy, tq.x0 / E_TW, hh, kk, PH, p.tiles_x, p.K) * 2) : (int)0x80000000;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rcd, off, 0, 0);
+        return *reinterpret_cast<const uint4*>(&v);
+    };
+    const int d_off = ((h * 128) + wave * 32 + r) * 2;    // + (rt * 8 + 2 q) * 256
+    const int c_off = (h * 128 + wave * 32 + r) * 2;      // + rt * 512
+    // gather base of the lane's column (tap, c) in each column tile, + 2 window columns for h = 1
+    int g_off[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        int col = ct * 32 + r;
+        if (col >= a.ncols) col = 0;
+        const int tap = col / a.Creal, ch = col - tap * a.Creal;
+        g_off[ct] = ((tap / 3) * E_PW + tap % 3) * E_ROWB + 2 * ch + 2 * h * E_ROWB;
+    }
+
+    f32x16 accA1[NCT], accG[NP];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accA1[ct][i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accG[q][i] = 0.f;
+    float m1 = 0.f;
+
+    uint4 pre[E_PLOADS], pred[E_DLOADS], prec;
+    int t = blockIdx.x;
+    TilePos tp = tile_pos(p, t < p.ntiles ? t : 0);
+    load_patch(p, rs, tp, t < p.ntiles, pre);
+    load_dyt(tp, t < p.ntiles, pred);
+    prec = load_codes(tp, t < p.ntiles);
+    for (; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();                 // everyone is done with the previous tile's patch, gradients, codes, fragments
+        store_patch<false>(sP, pre);
+#pragma unroll
+        for (int j = 0; j < E_DLOADS; ++j) *reinterpret_cast<uint4*>(sD + (threadIdx.x + j * E_NT) * 16) = pred[j];
+        *reinterpret_cast<uint4*>(sC + threadIdx.x * 16) = prec;
+        __syncthreads();
+        const TilePos cur = tp;
+        const int tn = t + gridDim.x;
+        tp = tile_pos(p, tn < p.ntiles ? tn : 0);
+        load_patch(p, rs, tp, tn < p.ntiles, pre);
+        load_dyt(tp, tn < p.ntiles, pred);
+        prec = load_codes(tp, tn < p.ntiles);
+        const bool full = cur.y0 + E_TH <= p.H && cur.x0 + E_TW <= p.W;
+        // ---- fragments of the tile: step = 2 rt + s2 (16 pixels: windows 4 s2 + {0, 2} + h of window
+        // row rt), column tile ct; this wave builds the fragments of steps wave, wave + 4, wave + 8, wave + 12
+        auto build = [&](auto FULL) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int step = wave + 4 * i;
+                const int rt = step >> 1, s2 = step & 1;
+                const char* prow = sP + 2 * rt * E_PW * E_ROWB;
+                unsigned keep[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // output pixels beyond the image do not exist: their patches must not enter the Gram matrix
+                    const int win = 4 * s2 + 2 * (j >> 2), e = j & 3;
+                    const int gy = cur.y0 + 2 * rt + (e >> 1), gx = cur.x0 + 2 * (win + h) + (e & 1);
+                    keep[j] = (decltype(FULL)::value || (gy < p.H && gx < p.W)) ? 0xffffu : 0u;
+                }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    unsigned xs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int win = 4 * s2 + 2 * (j >> 2), e = j & 3;     // + h via g_off
+                        const int off = ((e >> 1) * E_PW + 2 * win + (e & 1)) * E_ROWB;
+                        xs[j] = (unsigned)*reinterpret_cast<const unsigned short*>(prow + g_off[ct] + off) & keep[j];
+                    }
+                    uint4 xw;
+                    xw.x = xs[0] | (xs[1] << 16); xw.y = xs[2] | (xs[3] << 16);
+                    xw.z = xs[4] | (xs[5] << 16); xw.w = xs[6] | (xs[7] << 16);
+                    *reinterpret_cast<uint4*>(sX + (step * NCT + ct) * 1024 + lane * 16) = xw;
+                }
+            }
+        };
+        if (full) build(std::true_type{});
+        else build(std::false_type{});
+        __syncthreads();
+        // ---- A1 += dzm^T xp for this wave's channel tile
+        if (active) {
+#pragma unroll 2
+            for (int rt = 0; rt < 8; ++rt) {
+                const unsigned cw = *reinterpret_cast<const unsigned short*>(sC + c_off + rt * 512);
+                unsigned dp[8];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned gc = *reinterpret_cast<const unsigned short*>(sD + d_off + (rt * 8 + 2 * g) * 256);
+                    const unsigned code = (cw >> (3 * g)) & 7u, pos = code & 3u;
+                    const unsigned g16 = (code & 4u) ? gc : 0u;          // ReLU: no gradient through a maximum <= 0
+                    m1 += __uint_as_float(g16 << 16);
+                    const unsigned ghi = g16 << 16;
+                    dp[2 * g] = pos == 0u ? g16 : (pos == 1u ? ghi : 0u);
+                    dp[2 * g + 1] = pos == 2u ? g16 : (pos == 3u ? ghi : 0u);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 fd = *reinterpret_cast<const bf16x8*>(dp + 4 * s2);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const bf16x8 fx = *reinterpret_cast<const bf16x8*>(sX + ((2 * rt + s2) * NCT + ct) * 1024 + lane * 16);
+                        accA1[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd, fx, accA1[ct], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- G += xp^T xp: this wave takes steps 4 wave .. 4 wave + 3
+        if (gram) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int step = wave * 4 + q;
+                bf16x8 fr[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) fr[ct] = *reinterpret_cast<const bf16x8*>(sX + (step * NCT + ct) * 1024 + lane * 16);
+#pragma unroll
+                for (int ca = 0; ca < NCT; ++ca)
+#pragma unroll
+                    for (int cb = ca; cb < NCT; ++cb)
+                        accG[gram_pair(ca, cb, NCT)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ca], fr[cb], accG[gram_pair(ca, cb, NCT)], 0, 0, 0);
+            }
+        }
+    }
+    // ---- slab: every element written (zeros from idle waves), no atomics
+    float* slab = a.slab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * slab2_floats(NCT);
+    constexpr int ncp = NCT * 32;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = wave * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            slab[(size_t)row * ncp + ct * 32 + r] = accA1[ct][i];
+        }
+    const float t1 = m1 + __shfl_xor(m1, 32, 64);
+    if (h == 0) slab[(size_t)128 * ncp + wave * 32 + r] = t1;
+    // ---- Gram matrix of the workgroup: the four waves' parts added in wave order through LDS
+    if (gram) {
+        float* red = reinterpret_cast<float*>(smem);          // [NP][16][64]
+        for (int w2 = 0; w2 < 4; ++w2) {
+            __syncthreads();
+            if (wave == w2) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float* e = red + (q * 16 + i) * 64 + lane;
+                        *e = w2 == 0 ? accG[q][i] : *e + accG[q][i];
+                    }
+            }
+        }
+        __syncthreads();
+        float* gs = a.gslab + (size_t)blockIdx.x * NP * 1024;
+        for (int idx = threadIdx.x; idx < NP * 1024; idx += E_NT) {
+            const int q = idx >> 10, i = (idx >> 6) & 15, l = idx & 63;
+            const int m = 8 * (i >> 2) + 4 * (l >> 5) + (i & 3), n = l & 31;
+            gs[q * 1024 + m * 32 + n] = red[idx];
+        }
+    }
+}
+
+// sum of the workgroups' partial Gram matrices, in slab order (reproducible), in double
+__global__ __launch_bounds__(256) void enc1_gram_fold_kernel(const float* __restrict__ gslab, int nslabs, int n,
+                                                             double* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    double acc = 0.0;
+    for (int i0 = 0; i0 < nslabs; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gslab[(size_t)(i0 + u < nslabs ? i0 + u : i0) * n + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += i0 + u < nslabs ? (double)v[u] : 0.0;
+    }
+    out[e] = acc;
+}
+
 // Sums of the input the patch sums S are made of: per 8-channel half, over all images, the sum of
 // every pixel (0), of the first / last row (1, 2), of the first / last column (3, 4) and of the
 // four corners (5: (0,0), 6: (0,W-1), 7: (H-1,0), 8: (H-1,W-1)).  One slab [9][16] per workgroup.
@@ -597,6 +858,91 @@ __global__ __launch_bounds__(1024) void enc1_bwd_finalize_kernel(const float* __
     if (col == 0) { dgamma[k] = (float)m2; dbeta[k] = (float)m1; }
 }
 
+// The same gradients from the code-routed kernel's sums (enc1_bwd2_kernel): A1 and sum dzm from the
+// slabs, S from the input sums, and through the layer's own weights
+//     sum dzm * z = sum_col W[k][col] A1[k][col],     A2[k][col] = sum_col' W[k][col'] G[col'][col].
+__global__ __launch_bounds__(1024) void enc1_bwd2_finalize_kernel(const float* __restrict__ slabs, int nslabs,
+                                                                 const float* __restrict__ insums,
+                                                                 const double* __restrict__ gram, const bf16* __restrict__ w,
+                                                                 int K, int nct, int Creal, double inv_m, int training,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, float* __restrict__ dw,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int PARTS = 8;
+    __shared__ double sh[PARTS][3][128];
+    __shared__ double prod[128];
+    __shared__ float wrow[128];
+    const int ncp = nct * 32, ncols = 9 * Creal;
+    const size_t sf_ = slab2_floats(nct);
+    const int k = blockIdx.x, col = threadIdx.x & 127, part = threadIdx.x >> 7;
+    const int grp = k / 128, kk = k - grp * 128;
+    const bool live = col < ncols;
+    const int cc = live ? col : 0;
+    const int tap = cc / Creal, c = cc - tap * Creal, ty = tap / 3, tx = tap % 3;
+    double a1 = 0.0, m1 = 0.0, s = 0.0;
+    const float* base = slabs + (size_t)grp * nslabs * sf_;
+    for (int i0 = part; i0 < nslabs; i0 += PARTS * 8) {
+        float v1[8], v3[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * PARTS;
+            const float* sl = base + (size_t)(i < nslabs ? i : i0) * sf_;
+            v1[u] = sl[(size_t)kk * ncp + cc];
+            v3[u] = sl[(size_t)128 * ncp + kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = i0 + u * PARTS < nslabs;
+            a1 += ok ? (double)v1[u] : 0.0;
+            m1 += ok ? (double)v3[u] : 0.0;
+        }
+    }
+    const int rowq = ty == 0 ? 2 : 1, colq = tx == 0 ? 4 : 3;
+    const int corq = ty == 0 ? (tx == 0 ? 8 : 7) : (tx == 0 ? 6 : 5);
+    const double fr = ty != 1 ? 1.0 : 0.0, fc = tx != 1 ? 1.0 : 0.0, fk = (ty != 1 && tx != 1) ? 1.0 : 0.0;
+    for (int i0 = part; i0 < E_SUMS_GRID; i0 += PARTS * 4) {
+        float q0[4], q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PARTS;
+            const float* q = insums + (size_t)(i < E_SUMS_GRID ? i : i0) * 144 + c;
+            q0[u] = q[0]; q1[u] = q[rowq * 16]; q2[u] = q[colq * 16]; q3[u] = q[corq * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * PARTS < E_SUMS_GRID) s += (double)q0[u] - fr * (double)q1[u] - fc * (double)q2[u] + fk * (double)q3[u];
+    }
+    sh[part][0][col] = a1; sh[part][1][col] = m1; sh[part][2][col] = s;
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int q = 1; q < PARTS; ++q) { a1 += sh[q][0][col]; m1 += sh[q][1][col]; s += sh[q][2][col]; }
+        const float wv = live ? (float)w[((size_t)k * 9 + tap) * 16 + c] : 0.f;
+        wrow[col] = wv;
+        prod[col] = live ? (double)wv * a1 : 0.0;
+    }
+    __syncthreads();
+    if (part != 0 || !live) return;
+    double m2 = 0.0;
+    for (int q = 0; q < ncols; ++q) m2 += prod[q];                  // sum dzm * z, fixed order
+    m2 = (double)invstd[k] * (m2 - (double)mean[k] * m1);           // sum dzm * xhat
+    double g = a1;
+    if (training) {
+        double a2 = 0.0;
+        const int cb = col >> 5, cn = col & 31;
+        for (int q = 0; q < ncols; ++q) {
+            const int qa = q >> 5, qm = q & 31;
+            const double gv = qa <= cb ? gram[(size_t)gram_pair(qa, cb, nct) * 1024 + qm * 32 + cn]
+                                       : gram[(size_t)gram_pair(cb, qa, nct) * 1024 + cn * 32 + qm];
+            a2 += (double)wrow[q] * gv;
+        }
+        g = a1 - m1 * inv_m * s - m2 * inv_m * (double)invstd[k] * (a2 - (double)mean[k] * s);
+    }
+    dw[((size_t)k * Creal + c) * 9 + tap] = (float)((double)scale[k] * g);
+    if (col == 0) { dgamma[k] = (float)m2; dbeta[k] = (float)m1; }
+}
+
 int fill(E1Params& p, const char* who, const void* x, const void* w, int N, int H, int W, int K) {
     if (!x || !w || N <= 0 || H < 2 || W < 2 || (K != 128 && K != 256) ||
         (long long)N * H * W * E_ROWB >= 0x7fffffffLL) {
@@ -608,7 +954,7 @@ int fill(E1Params& p, const char* who, const void* x, const void* w, int N, int 
     p.tiles_x = (W + E_TW - 1) / E_TW;
     p.tiles_y = (H + E_TH - 1) / E_TH;
     p.ntiles = N * p.tiles_x * p.tiles_y;
-    p.ws = nullptr; p.scale = p.shift = nullptr; p.y = nullptr;
+    p.ws = nullptr; p.scale = p.shift = nullptr; p.y = nullptr; p.codes = nullptr;
     return SF_OK;
 }
 
@@ -644,12 +990,17 @@ extern "C" int sf_enc1_stats(const void* x, const void* w, double* ws, int N, in
     return launch<E_STATS>(p, (hipStream_t)stream, "sf_enc1_stats");
 }
 
-extern "C" int sf_enc1_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H,
-                           int W, int K, void* stream) {
+extern "C" size_t sf_enc1_codes_bytes(int N, int H, int W, int K) {
+    return (size_t)N * (H / 2) * ((W + E_TW - 1) / E_TW) * 2 * K * sizeof(unsigned short);
+}
+
+extern "C" int sf_enc1_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, void* codes,
+                           int N, int H, int W, int K, void* stream) {
     E1Params p;
     if (int rc = fill(p, "sf_enc1_fwd", x, w, N, H, W, K)) return rc;
     SF_REQUIRE(scale && shift && y, "sf_enc1_fwd: null argument");
-    p.scale = scale; p.shift = shift; p.y = (bf16*)y;
+    SF_REQUIRE(!codes || sf_enc1_codes_bytes(N, H, W, K) < 0x7fffffffULL, "sf_enc1_fwd: the routing codes exceed 2 GiB");
+    p.scale = scale; p.shift = shift; p.y = (bf16*)y; p.codes = (unsigned short*)codes;
     return launch<E_FWD>(p, (hipStream_t)stream, "sf_enc1_fwd");
 }
 
@@ -657,12 +1008,52 @@ extern "C" size_t sf_enc1_bwd_workspace_bytes(int N, int H, int W, int K, int Cr
     const int nct = (9 * Creal + 31) / 32;
     const long long ntiles = (long long)N * ((W + E_TW - 1) / E_TW) * ((H + E_TH - 1) / E_TH);
     const long long gx = ntiles < 512 ? ntiles : 512;
-    return sizeof(float) * (slab_floats(K, nct) * (size_t)gx * (size_t)((K + 127) / 128) + (size_t)E_SUMS_GRID * 144);
+    const size_t gy = (size_t)((K + 127) / 128);
+    // recomputing kernel: slabs + input sums; code-routed kernel: slabs + Gram slabs + folded Gram matrix (doubles) + input sums
+    const size_t a = slab_floats(K, nct) * (size_t)gx * gy + (size_t)E_SUMS_GRID * 144;
+    const size_t b = slab2_floats(nct) * (size_t)gx * gy + (size_t)gram_pairs(nct) * 1024 * ((size_t)gx + 2) + (size_t)E_SUMS_GRID * 144;
+    return sizeof(float) * (a > b ? a : b);
 }
 
-extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const float* scale, const float* shift,
-                           const float* mean, const float* invstd, int training, float* dw, float* dgamma, float* dbeta,
-                           float* ws, size_t ws_bytes, int N, int H, int W, int K, int Creal, void* stream) {
+// the code-routed path (enc1_bwd2_kernel): up to three column tiles (at most 10 real input channels)
+static int enc1_bwd_routed(const E1Params& c, const void* dy, const void* codes, const float* scale, const float* mean,
+                           const float* invstd, int training, float* dw, float* dgamma, float* dbeta, float* ws, int Creal,
+                           hipStream_t s) {
+    E1Bwd2 a;
+    a.c = c;
+    a.dy = (const bf16*)dy; a.codes = (const unsigned short*)codes;
+    a.Creal = Creal; a.ncols = 9 * Creal; a.gram = training ? 1 : 0;
+    const int nct = (a.ncols + 31) / 32, np = gram_pairs(nct);
+    const int gx = c.ntiles < 512 ? c.ntiles : 512, gy = (c.K + 127) / 128;
+    a.slab = ws;
+    a.gslab = ws + slab2_floats(nct) * (size_t)gx * (size_t)gy;
+    double* gsum = reinterpret_cast<double*>(a.gslab + (size_t)gx * np * 1024);      // (offsets are multiples of 128 floats: aligned)
+    float* insums = reinterpret_cast<float*>(gsum + (size_t)np * 1024);
+    const size_t lds = (size_t)E_PP * E_ROWB + (size_t)E_DCH * 16 + 8 * 2 * 128 * 2 + (size_t)16 * nct * 1024;
+    void (*kern)(E1Bwd2) = nct == 1 ? enc1_bwd2_kernel<1> : nct == 2 ? enc1_bwd2_kernel<2> : enc1_bwd2_kernel<3>;
+    static DeviceOnce attr_set[3];
+    DeviceOnce& once = attr_set[nct - 1];
+    if (!once.done()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            sf_set_error("sf_enc1_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
+            return SF_ELAUNCH;
+        }
+        once.mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(E_NT), lds, s, a);
+    hipLaunchKernelGGL(enc1_input_sums_kernel, dim3(E_SUMS_GRID), dim3(E_NT), 0, s, c.x, insums, c.N, c.H, c.W);
+    if (training)
+        hipLaunchKernelGGL(enc1_gram_fold_kernel, dim3((np * 1024 + 255) / 256), dim3(256), 0, s, a.gslab, gx, np * 1024, gsum);
+    hipLaunchKernelGGL(enc1_bwd2_finalize_kernel, dim3(c.K), dim3(1024), 0, s, ws, gx, insums, gsum, c.w, c.K, nct, Creal,
+                       1.0 / ((double)c.N * c.H * c.W), training, scale, mean, invstd, dw, dgamma, dbeta);
+    SF_LAUNCH_CHECK("sf_enc1_bwd");
+    return SF_OK;
+}
+
+extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const void* codes, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, int training, float* dw,
+                           float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int N, int H, int W, int K, int Creal,
+                           void* stream) {
     E1Bwd a;
     if (int rc = fill(a.c, "sf_enc1_bwd", x, w, N, H, W, K)) return rc;
     SF_REQUIRE(dy && scale && shift && mean && invstd && dw && dgamma && dbeta && ws, "sf_enc1_bwd: null argument");
@@ -670,6 +1061,11 @@ extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const f
     SF_REQUIRE((long long)N * (H / 2) * (W / 2) * K * 2 < 0x7fffffffLL, "sf_enc1_bwd: pooled gradient exceeds 2 GiB");
     const size_t need = sf_enc1_bwd_workspace_bytes(N, H, W, K, Creal);
     SF_REQUIRE(ws_bytes >= need, "sf_enc1_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    SF_REQUIRE(((uintptr_t)ws % 8) == 0, "sf_enc1_bwd: the workspace must be 8-byte aligned");
+    if (codes && 9 * Creal <= 96 && sf_enc1_codes_bytes(N, H, W, K) < 0x7fffffffULL) {
+        a.c.scale = scale; a.c.shift = shift;
+        return enc1_bwd_routed(a.c, dy, codes, scale, mean, invstd, training, dw, dgamma, dbeta, ws, Creal, (hipStream_t)stream);
+    }
     a.c.scale = scale; a.c.shift = shift;
     a.dy = (const bf16*)dy; a.mean = mean; a.invstd = invstd; a.slab = ws;
     a.Creal = Creal; a.ncols = 9 * Creal;

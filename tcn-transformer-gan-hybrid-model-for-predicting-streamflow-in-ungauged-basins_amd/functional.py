@@ -100,8 +100,12 @@ class EncoderFn(torch.autograd.Function):
                     ws = torch.empty(2 * K, device=x.device, dtype=torch.float64)
                     ops.enc1_stats(a, wp, K, ws)
                 st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, training)
-                saved.append((a, None, st, (h, w), wp))
-                a = ops.enc1_fwd(a, wp, st, K)
+                # with gradients wanted the forward also leaves each pooling window's arg-max and ReLU
+                # bit, so that the backward routes the pooled gradient without recomputing the conv
+                want = any(ctx.needs_input_grad[5 + 5 * l: 8 + 5 * l]) and wt.shape[1] <= 10
+                y0, codes = ops.enc1_fwd(a, wp, st, K, want_codes=True) if want else (ops.enc1_fwd(a, wp, st, K), None)
+                saved.append((a, None, st, (h, w), (wp, codes)))
+                a = y0
                 h, w = h // 2, w // 2
                 continue
             z = torch.empty((N, h, w, Kpad), device=x.device, dtype=cdtype)
@@ -149,7 +153,8 @@ class EncoderFn(torch.autograd.Function):
             a, z, st, (h, w), wp = ctx.saved[l]
             cin_real = wt.shape[1]
             if z is None:   # fused first layer: weight / BatchNorm gradients straight from the input
-                dw, dgamma, dbeta = ops.enc1_bwd(a, wp, dy, st, training, wt.shape[0], cin_real)
+                wp, codes = wp
+                dw, dgamma, dbeta = ops.enc1_bwd(a, wp, dy, st, training, wt.shape[0], cin_real, codes=codes)
                 grads[5 * l], grads[5 * l + 1], grads[5 * l + 2] = dw, dgamma, dbeta
                 continue
             K, Kpad, C = wt.shape[0], z.shape[-1], a.shape[-1]

@@ -62,6 +62,7 @@ def lib():
         L.sf_wgrad4x4s2_workspace_bytes.restype = ctypes.c_size_t
         L.sf_conv_k1_fwd_workspace_bytes.restype = ctypes.c_size_t
         L.sf_enc1_bwd_workspace_bytes.restype = ctypes.c_size_t
+        L.sf_enc1_codes_bytes.restype = ctypes.c_size_t
         L.sf_date_image_metrics_workspace_bytes.restype = ctypes.c_size_t
         L.sf_gru_save_floats.restype = ctypes.c_size_t
         L.sf_attn_save_floats.restype = ctypes.c_size_t
@@ -72,7 +73,7 @@ def lib():
 EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_tile_shape", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nchw_to_nhwc_checked", "sf_nchw_bf16_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_bn_relu_avgpool_fwd_moments", "sf_bn_bwd_reduce_pooled", "sf_channel_sum", "sf_colsum_f32",
-           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
+           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_codes_bytes", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
            "sf_conv_k1_fwd", "sf_conv_k1_fwd_ws", "sf_conv_k1_fwd_workspace_bytes", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss", "sf_image_station_loss_fwd", "sf_image_station_loss_bwd", "sf_image_station_loss_static",
@@ -663,25 +664,38 @@ def enc1_stats(x, wp, K, ws):
     _check(lib().sf_enc1_stats(_p(x), _p(wp), _p(ws), N, H, W, K, _stream()), "sf_enc1_stats")
 
 
-def enc1_fwd(x, wp, st, K):
+# False (or SF_ENC1_ROUTED=0 in the environment): the backward recomputes conv + arg-max instead of
+# using the forward's routing codes (A/B timing, tests)
+ENC1_ROUTED = os.environ.get("SF_ENC1_ROUTED", "1") != "0"
+
+
+def enc1_fwd(x, wp, st, K, want_codes: bool = False):
+    """Pooled activation of the fused first encoder layer; with want_codes also the routing codes
+    (uint8 buffer of sf_enc1_codes_bytes bytes) that sf_enc1_bwd can use, else None."""
     _dev(x, wp, st)
     N, H, W, _ = x.shape
     y = torch.empty((N, H // 2, W // 2, K), device=x.device, dtype=torch.bfloat16)
-    _check(lib().sf_enc1_fwd(_p(x), _p(wp), _p(st[0]), _p(st[1]), _p(y), N, H, W, K, _stream()), "sf_enc1_fwd")
-    return y
+    codes = None
+    if want_codes and ENC1_ROUTED:
+        nbytes = int(lib().sf_enc1_codes_bytes(N, H, W, K))
+        if nbytes < 2 ** 31 - 1:
+            codes = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    _check(lib().sf_enc1_fwd(_p(x), _p(wp), _p(st[0]), _p(st[1]), _p(y), _p(codes), N, H, W, K, _stream()), "sf_enc1_fwd")
+    return (y, codes) if want_codes else y
 
 
-def enc1_bwd(x, wp, dy, st, training, K, Creal):
-    """(dw [K,Creal,3,3], dgamma, dbeta) of the fused first encoder layer; st = bn_finalize rows."""
-    _dev(x, wp, dy, st)
+def enc1_bwd(x, wp, dy, st, training, K, Creal, codes=None):
+    """(dw [K,Creal,3,3], dgamma, dbeta) of the fused first encoder layer; st = bn_finalize rows;
+    codes = what enc1_fwd(..., want_codes=True) returned for the same inputs, or None."""
+    _dev(x, wp, dy, st, codes)
     N, H, W, _ = x.shape
     nbytes = int(lib().sf_enc1_bwd_workspace_bytes(N, H, W, K, Creal))
-    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    ws = torch.empty((nbytes + 7) // 8, device=x.device, dtype=torch.float64)      # 8-byte aligned
     dw = torch.empty((K, Creal, 3, 3), device=x.device, dtype=torch.float32)
     dgamma = torch.empty(K, device=x.device, dtype=torch.float32)
     dbeta = torch.empty(K, device=x.device, dtype=torch.float32)
-    _check(lib().sf_enc1_bwd(_p(x), _p(wp), _p(dy), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), int(training), _p(dw),
-                             _p(dgamma), _p(dbeta), _p(ws), ctypes.c_size_t(nbytes), N, H, W, K, Creal, _stream()),
+    _check(lib().sf_enc1_bwd(_p(x), _p(wp), _p(dy), _p(codes), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), int(training),
+                             _p(dw), _p(dgamma), _p(dbeta), _p(ws), ctypes.c_size_t(nbytes), N, H, W, K, Creal, _stream()),
            "sf_enc1_bwd")
     return dw, dgamma, dbeta
 

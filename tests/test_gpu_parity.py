@@ -671,6 +671,19 @@ def test_enc1_fused_layer_against_separate_kernels(sf):
         close(dbeta, dbeta_ref.cpu().numpy(), 2e-3)
         close(dgamma, dgamma_ref.cpu().numpy(), 2e-3)
         close(dw, dw_ref.cpu().numpy(), 2e-2)
+        # the same gradients routed by the forward pass's codes (no conv, no arg-max in the backward;
+        # the conv output enters through the weights times the Gram matrix of the input patches, not
+        # rounded to bf16 on the way): against the separate kernels as above, and against the
+        # recomputing kernel, from which only that rounding separates it
+        a2, codes = ops.enc1_fwd(x, wp, st, K, want_codes=True)
+        assert torch.equal(a2, a) and codes is not None
+        dw2, dgamma2, dbeta2 = ops.enc1_bwd(x, wp, dy, st, training, K, Cin, codes=codes)
+        close(dbeta2, dbeta_ref.cpu().numpy(), 2e-3)
+        close(dgamma2, dgamma_ref.cpu().numpy(), 2e-3)
+        close(dw2, dw_ref.cpu().numpy(), 2e-2)
+        close(dbeta2, dbeta.cpu().numpy(), 1e-5)
+        close(dgamma2, dgamma.cpu().numpy(), 1e-3)
+        close(dw2, dw.cpu().numpy(), 3e-3)
 
 
 def test_evaluator_against_reference_metrics(sf):
