@@ -285,12 +285,28 @@ int sf_enc1_fwd(const void* x, const void* w, const float* scale, const float* s
  *                  routed by them and everything that involves the conv output comes from two
  *                  channel-independent sums (the correlation of the routed gradient with the
  *                  input patches, and the patches' Gram matrix), so neither the conv nor the
- *                  arg-max is computed again; without, both are recomputed from x. */
+ *                  arg-max is computed again; without, both are recomputed from x.  gram: the
+ *                  record of sf_enc1_gram for the same x, or NULL (only read with codes). */
 size_t sf_enc1_bwd_workspace_bytes(int N, int H, int W, int K, int Creal);
-int sf_enc1_bwd(const void* x, const void* w, const void* dy, const void* codes, const float* scale,
-                const float* shift, const float* mean, const float* invstd, int training, float* dw,
-                float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int N, int H, int W, int K,
-                int Creal, void* stream);
+int sf_enc1_bwd(const void* x, const void* w, const void* dy, const void* codes, const double* gram,
+                const float* scale, const float* shift, const float* mean, const float* invstd,
+                int training, float* dw, float* dgamma, float* dbeta, float* ws, size_t ws_bytes,
+                int N, int H, int W, int K, int Creal, void* stream);
+/* The Gram record of the layer's input: G = sum over the output pixels of xp xp^T, xp the 9 * Creal
+ * values of the pixel's 3x3 input patch (upper-triangle 32 x 32 tiles), followed by the sums of the
+ * input over the image, its border rows / columns and corners (which give sum xp).  Both are
+ * independent of the weights and of the output channel, and everything the layer needs of its conv
+ * output z = W xp beyond single pixels is made of them:
+ *   sf_enc1_stats_gram: BatchNorm statistics, sum z = W . sum xp, sum z^2 = W G W^T (the record
+ *       sf_enc1_stats writes, but of the unrounded z) -- no pass over the conv output at all;
+ *   sf_enc1_bwd(gram = rec): the conv-output terms of the BatchNorm backward (otherwise that call
+ *       accumulates the record itself).
+ * Creal <= 10.  rec: SF_ENC1_GRAM_DOUBLES doubles; ws: sf_enc1_gram_workspace_bytes bytes. */
+#define SF_ENC1_GRAM_DOUBLES 6400
+size_t sf_enc1_gram_workspace_bytes(int N, int H, int W, int Creal);
+int sf_enc1_gram(const void* x, int N, int H, int W, int Creal, double* rec, float* ws,
+                 size_t ws_bytes, void* stream);
+int sf_enc1_stats_gram(const void* w, const double* rec, int K, int Creal, double* ws, void* stream);
 
 /* ---- bilinear resize, align_corners=False (src/model/decoder.py:165-170, src/loss.py:49-54) */
 /* src NHWC f32 [B,h,w,C] -> dst NHWC (dtype) [B,OH,OW,C]; C == Cpad */

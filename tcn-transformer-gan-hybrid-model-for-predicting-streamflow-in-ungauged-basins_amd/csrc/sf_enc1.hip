@@ -30,6 +30,7 @@ constexpr int E_PCHUNKS = E_PP * 2;          // 16-byte chunks of a patch
 constexpr int E_PLOADS = (E_PCHUNKS + E_NT - 1) / E_NT;
 
 enum { E_STATS = 0, E_FWD = 1 };
+constexpr int E_SUMS_GRID = 1024;          // workgroups (and slabs) of enc1_input_sums_kernel
 
 struct E1Params {
     const bf16* x;       // [N,H,W,16]
@@ -500,9 +501,12 @@ __host__ __device__ inline size_t slab2_floats(int nct) { return (size_t)128 * n
 __host__ __device__ inline int gram_pairs(int nct) { return nct * (nct + 1) / 2; }
 __host__ __device__ inline int gram_pair(int a, int b, int nct) { return a * nct - a * (a - 1) / 2 + (b - a); }   // a <= b
 
-template <int NCT>
+// MODE 0: A1 and sum dzm only (the Gram matrix is at hand already); 1: both; 2: the Gram matrix only
+// (a pass over the input alone: no gradients, no codes).
+template <int NCT, int MODE>
 __global__ __launch_bounds__(E_NT, 2) void enc1_bwd2_kernel(E1Bwd2 a) {
-    constexpr int NP = NCT * (NCT + 1) / 2, NF = 16 * NCT;        // column-tile pairs; fragments per tile
+    constexpr bool GRAM = MODE != 0, WANT_A1 = MODE != 2;
+    constexpr int NP = GRAM ? NCT * (NCT + 1) / 2 : 1;            // column-tile pairs accumulated here
     const E1Params& p = a.c;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sP = smem;                                   // halo patch [E_PP][16 channels]
@@ -512,8 +516,8 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd2_kernel(E1Bwd2 a) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kt = blockIdx.y * 4 + wave;
-    const bool active = kt * 32 < p.K;
-    const bool gram = a.gram && blockIdx.y == 0;
+    const bool active = WANT_A1 && kt * 32 < p.K;
+    const bool gram = GRAM && blockIdx.y == 0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.x, 0, (unsigned)((size_t)p.N * p.H * p.W * E_ROWB), 0x00020000);
     const int PH = p.H / 2, PWd = p.W / 2;
@@ -569,21 +573,27 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd2_kernel(E1Bwd2 a) {
     int t = blockIdx.x;
     TilePos tp = tile_pos(p, t < p.ntiles ? t : 0);
     load_patch(p, rs, tp, t < p.ntiles, pre);
-    load_dyt(tp, t < p.ntiles, pred);
-    prec = load_codes(tp, t < p.ntiles);
+    if constexpr (WANT_A1) {
+        load_dyt(tp, t < p.ntiles, pred);
+        prec = load_codes(tp, t < p.ntiles);
+    }
     for (; t < p.ntiles; t += gridDim.x) {
         __syncthreads();                 // everyone is done with the previous tile's patch, gradients, codes, fragments
         store_patch<false>(sP, pre);
+        if constexpr (WANT_A1) {
 #pragma unroll
-        for (int j = 0; j < E_DLOADS; ++j) *reinterpret_cast<uint4*>(sD + (threadIdx.x + j * E_NT) * 16) = pred[j];
-        *reinterpret_cast<uint4*>(sC + threadIdx.x * 16) = prec;
+            for (int j = 0; j < E_DLOADS; ++j) *reinterpret_cast<uint4*>(sD + (threadIdx.x + j * E_NT) * 16) = pred[j];
+            *reinterpret_cast<uint4*>(sC + threadIdx.x * 16) = prec;
+        }
         __syncthreads();
         const TilePos cur = tp;
         const int tn = t + gridDim.x;
         tp = tile_pos(p, tn < p.ntiles ? tn : 0);
         load_patch(p, rs, tp, tn < p.ntiles, pre);
-        load_dyt(tp, tn < p.ntiles, pred);
-        prec = load_codes(tp, tn < p.ntiles);
+        if constexpr (WANT_A1) {
+            load_dyt(tp, tn < p.ntiles, pred);
+            prec = load_codes(tp, tn < p.ntiles);
+        }
         const bool full = cur.y0 + E_TH <= p.H && cur.x0 + E_TW <= p.W;
         // ---- fragments of the tile: step = 2 rt + s2 (16 pixels: windows 4 s2 + {0, 2} + h of window
         // row rt), column tile ct; this wave builds the fragments of steps wave, wave + 4, wave + 8, wave + 12
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd2_kernel(E1Bwd2 a) {
             }
         }
         // ---- G += xp^T xp: this wave takes steps 4 wave .. 4 wave + 3
-        if (gram) {
+        if constexpr (GRAM) if (gram) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int step = wave * 4 + q;
@@ -664,19 +674,21 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd2_kernel(E1Bwd2 a) {
         }
     }
     // ---- slab: every element written (zeros from idle waves), no atomics
-    float* slab = a.slab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * slab2_floats(NCT);
-    constexpr int ncp = NCT * 32;
+    if constexpr (WANT_A1) {
+        float* slab = a.slab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * slab2_floats(NCT);
+        constexpr int ncp = NCT * 32;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = wave * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-            slab[(size_t)row * ncp + ct * 32 + r] = accA1[ct][i];
-        }
-    const float t1 = m1 + __shfl_xor(m1, 32, 64);
-    if (h == 0) slab[(size_t)128 * ncp + wave * 32 + r] = t1;
+            for (int i = 0; i < 16; ++i) {
+                const int row = wave * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                slab[(size_t)row * ncp + ct * 32 + r] = accA1[ct][i];
+            }
+        const float t1 = m1 + __shfl_xor(m1, 32, 64);
+        if (h == 0) slab[(size_t)128 * ncp + wave * 32 + r] = t1;
+    }
     // ---- Gram matrix of the workgroup: the four waves' parts added in wave order through LDS
-    if (gram) {
+    if constexpr (GRAM) if (gram) {
         float* red = reinterpret_cast<float*>(smem);          // [NP][16][64]
         for (int w2 = 0; w2 < 4; ++w2) {
             __syncthreads();
@@ -700,20 +712,71 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd2_kernel(E1Bwd2 a) {
     }
 }
 
-// sum of the workgroups' partial Gram matrices, in slab order (reproducible), in double
+// Sum of the workgroups' partial Gram matrices and of the input-sum slabs, in slab order
+// (reproducible), in double.  out: [n Gram entries][144 input sums] = the "Gram record" that the
+// statistics and the gradient finalize kernels read (SF_ENC1_GRAM_DOUBLES doubles at most).
 __global__ __launch_bounds__(256) void enc1_gram_fold_kernel(const float* __restrict__ gslab, int nslabs, int n,
-                                                             double* __restrict__ out) {
+                                                             const float* __restrict__ insums, double* __restrict__ out) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    if (e >= n + 144) return;
+    const float* src = e < n ? gslab + e : insums + (e - n);
+    const int cnt = e < n ? nslabs : E_SUMS_GRID;
+    const size_t stride = e < n ? (size_t)n : 144;
     double acc = 0.0;
-    for (int i0 = 0; i0 < nslabs; i0 += 8) {
+    for (int i0 = 0; i0 < cnt; i0 += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = gslab[(size_t)(i0 + u < nslabs ? i0 + u : i0) * n + e];
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(i0 + u < cnt ? i0 + u : i0) * stride];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += i0 + u < nslabs ? (double)v[u] : 0.0;
+        for (int u = 0; u < 8; ++u) acc += i0 + u < cnt ? (double)v[u] : 0.0;
     }
     out[e] = acc;
+}
+
+// S[(tap, c)] = sum over the output pixels of the input value under tap (ty, tx): every pixel of
+// the image except the border row / column the tap never reaches (tap row 0 never reads the last
+// image row, tap row 2 never the first; columns alike), from the folded input sums
+// [9][16] = all, first row, last row, first column, last column, four corners.
+__device__ __forceinline__ double patch_sum(const double* __restrict__ sums, int tap, int c) {
+    const int ty = tap / 3, tx = tap % 3;
+    const int rowq = ty == 0 ? 2 : 1, colq = tx == 0 ? 4 : 3;
+    const int corq = ty == 0 ? (tx == 0 ? 8 : 7) : (tx == 0 ? 6 : 5);
+    const double fr = ty != 1 ? 1.0 : 0.0, fc = tx != 1 ? 1.0 : 0.0, fk = (ty != 1 && tx != 1) ? 1.0 : 0.0;
+    return sums[c] - fr * sums[rowq * 16 + c] - fc * sums[colq * 16 + c] + fk * sums[corq * 16 + c];
+}
+__device__ __forceinline__ double gram_at(const double* __restrict__ gram, int qa_col, int qb_col, int nct) {
+    const int qa = qa_col >> 5, qm = qa_col & 31, cb = qb_col >> 5, cn = qb_col & 31;
+    return qa <= cb ? gram[(size_t)gram_pair(qa, cb, nct) * 1024 + qm * 32 + cn]
+                    : gram[(size_t)gram_pair(cb, qa, nct) * 1024 + cn * 32 + qm];
+}
+
+// BatchNorm statistics of the conv output without a pass over it: with z[p][k] = sum_col W[k][col] xp[p][col],
+//     sum_p z = W[k] . S        and        sum_p z^2 = W[k] G W[k]^T.
+// ws[k] = sum, ws[K + k] = sum of squares (the record sf_enc1_stats writes; here of the unrounded z).
+__global__ __launch_bounds__(128) void enc1_stats_gram_kernel(const double* __restrict__ rec, const bf16* __restrict__ w, int K,
+                                                              int nct, int Creal, double* __restrict__ ws) {
+    __shared__ float wrow[128];
+    __shared__ double red[2][128];
+    const int ncols = 9 * Creal, k = blockIdx.x, col = threadIdx.x;
+    const bool live = col < ncols;
+    const int cc = live ? col : 0, tap = cc / Creal, c = cc - tap * Creal;
+    const double* gram = rec;
+    const double* sums = rec + (size_t)gram_pairs(nct) * 1024;
+    const float wv = live ? (float)w[((size_t)k * 9 + tap) * 16 + c] : 0.f;
+    wrow[col] = wv;
+    __syncthreads();
+    double t = 0.0;
+    if (live)
+        for (int q = 0; q < ncols; ++q) t += (double)wrow[q] * gram_at(gram, q, col, nct);
+    red[0][col] = live ? (double)wv * patch_sum(sums, tap, c) : 0.0;
+    red[1][col] = live ? (double)wv * t : 0.0;
+    __syncthreads();
+    if (col == 0) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int q = 0; q < ncols; ++q) { s0 += red[0][q]; s1 += red[1][q]; }
+        ws[k] = s0;
+        ws[K + k] = s1 > 0.0 ? s1 : 0.0;
+    }
 }
 
 // Sums of the input the patch sums S are made of: per 8-channel half, over all images, the sum of
@@ -788,7 +851,6 @@ __global__ __launch_bounds__(E_NT) void enc1_input_sums_kernel(const bf16* __res
 // dgamma = m2, dbeta = m1.  Slabs are added in a fixed order (reproducible).  S[(tap, c)] = all - excluded border row - excluded border
 // column + their common corner (tap row 0 never reaches the last image row, tap row 2 never the
 // first; columns alike).
-constexpr int E_SUMS_GRID = 1024;
 __global__ __launch_bounds__(1024) void enc1_bwd_finalize_kernel(const float* __restrict__ slabs, int nslabs,
                                                                 const float* __restrict__ insums, int K, int nct,
                                                                 int Creal, double inv_m, int training,
@@ -862,15 +924,14 @@ __global__ __launch_bounds__(1024) void enc1_bwd_finalize_kernel(const float* __
 // slabs, S from the input sums, and through the layer's own weights
 //     sum dzm * z = sum_col W[k][col] A1[k][col],     A2[k][col] = sum_col' W[k][col'] G[col'][col].
 __global__ __launch_bounds__(1024) void enc1_bwd2_finalize_kernel(const float* __restrict__ slabs, int nslabs,
-                                                                 const float* __restrict__ insums,
-                                                                 const double* __restrict__ gram, const bf16* __restrict__ w,
+                                                                 const double* __restrict__ rec, const bf16* __restrict__ w,
                                                                  int K, int nct, int Creal, double inv_m, int training,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, float* __restrict__ dw,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
     constexpr int PARTS = 8;
-    __shared__ double sh[PARTS][3][128];
+    __shared__ double sh[PARTS][2][128];
     __shared__ double prod[128];
     __shared__ float wrow[128];
     const int ncp = nct * 32, ncols = 9 * Creal;
@@ -879,8 +940,10 @@ __global__ __launch_bounds__(1024) void enc1_bwd2_finalize_kernel(const float* _
     const int grp = k / 128, kk = k - grp * 128;
     const bool live = col < ncols;
     const int cc = live ? col : 0;
-    const int tap = cc / Creal, c = cc - tap * Creal, ty = tap / 3, tx = tap % 3;
-    double a1 = 0.0, m1 = 0.0, s = 0.0;
+    const int tap = cc / Creal, c = cc - tap * Creal;
+    const double* gram = rec;
+    const double* sums = rec + (size_t)gram_pairs(nct) * 1024;
+    double a1 = 0.0, m1 = 0.0;
     const float* base = slabs + (size_t)grp * nslabs * sf_;
     for (int i0 = part; i0 < nslabs; i0 += PARTS * 8) {
         float v1[8], v3[8];
@@ -898,26 +961,11 @@ __global__ __launch_bounds__(1024) void enc1_bwd2_finalize_kernel(const float* _
             m1 += ok ? (double)v3[u] : 0.0;
         }
     }
-    const int rowq = ty == 0 ? 2 : 1, colq = tx == 0 ? 4 : 3;
-    const int corq = ty == 0 ? (tx == 0 ? 8 : 7) : (tx == 0 ? 6 : 5);
-    const double fr = ty != 1 ? 1.0 : 0.0, fc = tx != 1 ? 1.0 : 0.0, fk = (ty != 1 && tx != 1) ? 1.0 : 0.0;
-    for (int i0 = part; i0 < E_SUMS_GRID; i0 += PARTS * 4) {
-        float q0[4], q1[4], q2[4], q3[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * PARTS;
-            const float* q = insums + (size_t)(i < E_SUMS_GRID ? i : i0) * 144 + c;
-            q0[u] = q[0]; q1[u] = q[rowq * 16]; q2[u] = q[colq * 16]; q3[u] = q[corq * 16];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i0 + u * PARTS < E_SUMS_GRID) s += (double)q0[u] - fr * (double)q1[u] - fc * (double)q2[u] + fk * (double)q3[u];
-    }
-    sh[part][0][col] = a1; sh[part][1][col] = m1; sh[part][2][col] = s;
+    sh[part][0][col] = a1; sh[part][1][col] = m1;
     __syncthreads();
     if (part == 0) {
 #pragma unroll
-        for (int q = 1; q < PARTS; ++q) { a1 += sh[q][0][col]; m1 += sh[q][1][col]; s += sh[q][2][col]; }
+        for (int q = 1; q < PARTS; ++q) { a1 += sh[q][0][col]; m1 += sh[q][1][col]; }
         const float wv = live ? (float)w[((size_t)k * 9 + tap) * 16 + c] : 0.f;
         wrow[col] = wv;
         prod[col] = live ? (double)wv * a1 : 0.0;
@@ -929,14 +977,9 @@ __global__ __launch_bounds__(1024) void enc1_bwd2_finalize_kernel(const float* _
     m2 = (double)invstd[k] * (m2 - (double)mean[k] * m1);           // sum dzm * xhat
     double g = a1;
     if (training) {
+        const double s = patch_sum(sums, tap, c);
         double a2 = 0.0;
-        const int cb = col >> 5, cn = col & 31;
-        for (int q = 0; q < ncols; ++q) {
-            const int qa = q >> 5, qm = q & 31;
-            const double gv = qa <= cb ? gram[(size_t)gram_pair(qa, cb, nct) * 1024 + qm * 32 + cn]
-                                       : gram[(size_t)gram_pair(cb, qa, nct) * 1024 + cn * 32 + qm];
-            a2 += (double)wrow[q] * gv;
-        }
+        for (int q = 0; q < ncols; ++q) a2 += (double)wrow[q] * gram_at(gram, q, col, nct);
         g = a1 - m1 * inv_m * s - m2 * inv_m * (double)invstd[k] * (a2 - (double)mean[k] * s);
     }
     dw[((size_t)k * Creal + c) * 9 + tap] = (float)((double)scale[k] * g);
@@ -1011,49 +1054,117 @@ extern "C" size_t sf_enc1_bwd_workspace_bytes(int N, int H, int W, int K, int Cr
     const size_t gy = (size_t)((K + 127) / 128);
     // recomputing kernel: slabs + input sums; code-routed kernel: slabs + Gram slabs + folded Gram matrix (doubles) + input sums
     const size_t a = slab_floats(K, nct) * (size_t)gx * gy + (size_t)E_SUMS_GRID * 144;
-    const size_t b = slab2_floats(nct) * (size_t)gx * gy + (size_t)gram_pairs(nct) * 1024 * ((size_t)gx + 2) + (size_t)E_SUMS_GRID * 144;
+    const size_t b = slab2_floats(nct) * (size_t)gx * gy + (size_t)gram_pairs(nct) * 1024 * (size_t)gx + 2 * (size_t)SF_ENC1_GRAM_DOUBLES +
+                     (size_t)E_SUMS_GRID * 144;
     return sizeof(float) * (a > b ? a : b);
 }
 
-// the code-routed path (enc1_bwd2_kernel): up to three column tiles (at most 10 real input channels)
-static int enc1_bwd_routed(const E1Params& c, const void* dy, const void* codes, const float* scale, const float* mean,
-                           const float* invstd, int training, float* dw, float* dgamma, float* dbeta, float* ws, int Creal,
-                           hipStream_t s) {
-    E1Bwd2 a;
-    a.c = c;
-    a.dy = (const bf16*)dy; a.codes = (const unsigned short*)codes;
-    a.Creal = Creal; a.ncols = 9 * Creal; a.gram = training ? 1 : 0;
-    const int nct = (a.ncols + 31) / 32, np = gram_pairs(nct);
-    const int gx = c.ntiles < 512 ? c.ntiles : 512, gy = (c.K + 127) / 128;
-    a.slab = ws;
-    a.gslab = ws + slab2_floats(nct) * (size_t)gx * (size_t)gy;
-    double* gsum = reinterpret_cast<double*>(a.gslab + (size_t)gx * np * 1024);      // (offsets are multiples of 128 floats: aligned)
-    float* insums = reinterpret_cast<float*>(gsum + (size_t)np * 1024);
+// launch of enc1_bwd2_kernel<nct, MODE> (its LDS limit raised once per device and variant)
+template <int MODE>
+static int launch_bwd2(const E1Bwd2& a, int nct, int gx, int gy, hipStream_t s, const char* who) {
     const size_t lds = (size_t)E_PP * E_ROWB + (size_t)E_DCH * 16 + 8 * 2 * 128 * 2 + (size_t)16 * nct * 1024;
-    void (*kern)(E1Bwd2) = nct == 1 ? enc1_bwd2_kernel<1> : nct == 2 ? enc1_bwd2_kernel<2> : enc1_bwd2_kernel<3>;
+    void (*kern)(E1Bwd2) = nct == 1 ? enc1_bwd2_kernel<1, MODE> : nct == 2 ? enc1_bwd2_kernel<2, MODE> : enc1_bwd2_kernel<3, MODE>;
     static DeviceOnce attr_set[3];
     DeviceOnce& once = attr_set[nct - 1];
     if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            sf_set_error("sf_enc1_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
+            sf_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", who, lds);
             return SF_ELAUNCH;
         }
         once.mark();
     }
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(E_NT), lds, s, a);
+    return SF_OK;
+}
+
+// Gram record of the input patches: partial matrices per workgroup, the input sums, both folded
+static int gram_record(const E1Params& c, int Creal, bool accumulate_here, float* gslab, float* insums, double* rec, int gx,
+                       hipStream_t s, const char* who) {
+    const int nct = (9 * Creal + 31) / 32, np = gram_pairs(nct);
+    if (accumulate_here) {
+        E1Bwd2 a;
+        a.c = c; a.dy = nullptr; a.codes = nullptr; a.slab = nullptr; a.gslab = gslab;
+        a.Creal = Creal; a.ncols = 9 * Creal; a.gram = 1;
+        if (int rc = launch_bwd2<2>(a, nct, gx, 1, s, who)) return rc;
+    }
     hipLaunchKernelGGL(enc1_input_sums_kernel, dim3(E_SUMS_GRID), dim3(E_NT), 0, s, c.x, insums, c.N, c.H, c.W);
-    if (training)
-        hipLaunchKernelGGL(enc1_gram_fold_kernel, dim3((np * 1024 + 255) / 256), dim3(256), 0, s, a.gslab, gx, np * 1024, gsum);
-    hipLaunchKernelGGL(enc1_bwd2_finalize_kernel, dim3(c.K), dim3(1024), 0, s, ws, gx, insums, gsum, c.w, c.K, nct, Creal,
+    hipLaunchKernelGGL(enc1_gram_fold_kernel, dim3((np * 1024 + 144 + 255) / 256), dim3(256), 0, s, gslab, gx, np * 1024, insums, rec);
+    return SF_OK;
+}
+
+static int gram_shape(E1Params& p, const char* who, const void* x, int N, int H, int W, int Creal) {
+    if (!x || N <= 0 || H < 2 || W < 2 || Creal < 1 || 9 * Creal > 96 || (long long)N * H * W * E_ROWB >= 0x7fffffffLL) {
+        sf_set_error("%s: unsupported shape N=%d H=%d W=%d with %d real channels (1..10)", who, N, H, W, Creal);
+        return SF_EINVAL;
+    }
+    p.x = (const bf16*)x; p.w = nullptr;
+    p.N = N; p.H = H; p.W = W; p.K = 128;
+    p.tiles_x = (W + E_TW - 1) / E_TW;
+    p.tiles_y = (H + E_TH - 1) / E_TH;
+    p.ntiles = N * p.tiles_x * p.tiles_y;
+    p.ws = nullptr; p.scale = p.shift = nullptr; p.y = nullptr; p.codes = nullptr;
+    return SF_OK;
+}
+
+extern "C" size_t sf_enc1_gram_workspace_bytes(int N, int H, int W, int Creal) {
+    const int nct = (9 * Creal + 31) / 32;
+    const long long ntiles = (long long)N * ((W + E_TW - 1) / E_TW) * ((H + E_TH - 1) / E_TH);
+    const long long gx = ntiles < 512 ? ntiles : 512;
+    return sizeof(float) * ((size_t)gram_pairs(nct) * 1024 * (size_t)gx + (size_t)E_SUMS_GRID * 144);
+}
+
+extern "C" int sf_enc1_gram(const void* x, int N, int H, int W, int Creal, double* rec, float* ws, size_t ws_bytes,
+                            void* stream) {
+    E1Params p;
+    if (int rc = gram_shape(p, "sf_enc1_gram", x, N, H, W, Creal)) return rc;
+    SF_REQUIRE(rec && ws, "sf_enc1_gram: null argument");
+    SF_REQUIRE(ws_bytes >= sf_enc1_gram_workspace_bytes(N, H, W, Creal), "sf_enc1_gram: workspace too small");
+    const int nct = (9 * Creal + 31) / 32, gx = p.ntiles < 512 ? p.ntiles : 512;
+    float* insums = ws + (size_t)gram_pairs(nct) * 1024 * gx;
+    if (int rc = gram_record(p, Creal, true, ws, insums, rec, gx, (hipStream_t)stream, "sf_enc1_gram")) return rc;
+    SF_LAUNCH_CHECK("sf_enc1_gram");
+    return SF_OK;
+}
+
+extern "C" int sf_enc1_stats_gram(const void* w, const double* rec, int K, int Creal, double* ws, void* stream) {
+    SF_REQUIRE(w && rec && ws && (K == 128 || K == 256) && Creal >= 1 && 9 * Creal <= 96, "sf_enc1_stats_gram: bad arguments");
+    hipLaunchKernelGGL(enc1_stats_gram_kernel, dim3(K), dim3(128), 0, (hipStream_t)stream, rec, (const bf16*)w, K,
+                       (9 * Creal + 31) / 32, Creal, ws);
+    SF_LAUNCH_CHECK("sf_enc1_stats_gram");
+    return SF_OK;
+}
+
+// the code-routed path (enc1_bwd2_kernel): up to three column tiles (at most 10 real input channels)
+static int enc1_bwd_routed(const E1Params& c, const void* dy, const void* codes, const double* rec, const float* scale,
+                           const float* mean, const float* invstd, int training, float* dw, float* dgamma, float* dbeta,
+                           float* ws, int Creal, hipStream_t s) {
+    E1Bwd2 a;
+    a.c = c;
+    a.dy = (const bf16*)dy; a.codes = (const unsigned short*)codes;
+    a.Creal = Creal; a.ncols = 9 * Creal;
+    const int nct = (a.ncols + 31) / 32, np = gram_pairs(nct);
+    const int gx = c.ntiles < 512 ? c.ntiles : 512, gy = (c.K + 127) / 128;
+    const bool here = training && !rec;             // the Gram record has to be made in this call
+    a.gram = here ? 1 : 0;
+    a.slab = ws;
+    a.gslab = ws + slab2_floats(nct) * (size_t)gx * (size_t)gy;
+    double* own = reinterpret_cast<double*>(a.gslab + (size_t)gx * np * 1024);      // (offsets are multiples of 128 floats: aligned)
+    float* insums = reinterpret_cast<float*>(own + SF_ENC1_GRAM_DOUBLES);
+    if (int rc = here ? launch_bwd2<1>(a, nct, gx, gy, s, "sf_enc1_bwd") : launch_bwd2<0>(a, nct, gx, gy, s, "sf_enc1_bwd")) return rc;
+    if (here) {
+        if (int rc = gram_record(c, Creal, false, a.gslab, insums, own, gx, s, "sf_enc1_bwd")) return rc;
+        rec = own;
+    }
+    hipLaunchKernelGGL(enc1_bwd2_finalize_kernel, dim3(c.K), dim3(1024), 0, s, ws, gx, rec, c.w, c.K, nct, Creal,
                        1.0 / ((double)c.N * c.H * c.W), training, scale, mean, invstd, dw, dgamma, dbeta);
     SF_LAUNCH_CHECK("sf_enc1_bwd");
     return SF_OK;
 }
 
-extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const void* codes, const float* scale,
-                           const float* shift, const float* mean, const float* invstd, int training, float* dw,
-                           float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int N, int H, int W, int K, int Creal,
-                           void* stream) {
+extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const void* codes, const double* gram,
+                           const float* scale, const float* shift, const float* mean, const float* invstd, int training,
+                           float* dw, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int N, int H, int W, int K,
+                           int Creal, void* stream) {
     E1Bwd a;
     if (int rc = fill(a.c, "sf_enc1_bwd", x, w, N, H, W, K)) return rc;
     SF_REQUIRE(dy && scale && shift && mean && invstd && dw && dgamma && dbeta && ws, "sf_enc1_bwd: null argument");
@@ -1064,7 +1175,7 @@ extern "C" int sf_enc1_bwd(const void* x, const void* w, const void* dy, const v
     SF_REQUIRE(((uintptr_t)ws % 8) == 0, "sf_enc1_bwd: the workspace must be 8-byte aligned");
     if (codes && 9 * Creal <= 96 && sf_enc1_codes_bytes(N, H, W, K) < 0x7fffffffULL) {
         a.c.scale = scale; a.c.shift = shift;
-        return enc1_bwd_routed(a.c, dy, codes, scale, mean, invstd, training, dw, dgamma, dbeta, ws, Creal, (hipStream_t)stream);
+        return enc1_bwd_routed(a.c, dy, codes, gram, scale, mean, invstd, training, dw, dgamma, dbeta, ws, Creal, (hipStream_t)stream);
     }
     a.c.scale = scale; a.c.shift = shift;
     a.dy = (const bf16*)dy; a.mean = mean; a.invstd = invstd; a.slab = ws;

@@ -95,16 +95,24 @@ class EncoderFn(torch.autograd.Function):
                     and ops.enc1_ok(a, K) and not ops.FORCE_GENERIC_CONV):
                 # first layer: the conv output (the model's largest tensor) is never stored; the
                 # statistics, the pooled activation and later the gradients each recompute it
-                ws = None
+                ws, gram = None, None
+                routed = ops.ENC1_ROUTED and wt.shape[1] <= 10
                 if training:
                     ws = torch.empty(2 * K, device=x.device, dtype=torch.float64)
-                    ops.enc1_stats(a, wp, K, ws)
+                    if routed:
+                        # the batch statistics of z = W xp from the Gram matrix of the input patches
+                        # (sum z = W . sum xp, sum z^2 = W G W^T): one cheap pass over the 16-channel
+                        # input instead of a conv pass; the backward needs the same matrix again
+                        gram = ops.enc1_gram(a, wt.shape[1])
+                        ops.enc1_stats_gram(wp, gram, K, wt.shape[1], ws)
+                    else:
+                        ops.enc1_stats(a, wp, K, ws)
                 st = ops.bn_finalize(ws, M, K, K, gamma.detach(), beta.detach(), rm, rv, training)
                 # with gradients wanted the forward also leaves each pooling window's arg-max and ReLU
                 # bit, so that the backward routes the pooled gradient without recomputing the conv
-                want = any(ctx.needs_input_grad[5 + 5 * l: 8 + 5 * l]) and wt.shape[1] <= 10
+                want = routed and any(ctx.needs_input_grad[5 + 5 * l: 8 + 5 * l])
                 y0, codes = ops.enc1_fwd(a, wp, st, K, want_codes=True) if want else (ops.enc1_fwd(a, wp, st, K), None)
-                saved.append((a, None, st, (h, w), (wp, codes)))
+                saved.append((a, None, st, (h, w), (wp, codes, gram)))
                 a = y0
                 h, w = h // 2, w // 2
                 continue
@@ -153,8 +161,8 @@ class EncoderFn(torch.autograd.Function):
             a, z, st, (h, w), wp = ctx.saved[l]
             cin_real = wt.shape[1]
             if z is None:   # fused first layer: weight / BatchNorm gradients straight from the input
-                wp, codes = wp
-                dw, dgamma, dbeta = ops.enc1_bwd(a, wp, dy, st, training, wt.shape[0], cin_real, codes=codes)
+                wp, codes, gram = wp
+                dw, dgamma, dbeta = ops.enc1_bwd(a, wp, dy, st, training, wt.shape[0], cin_real, codes=codes, gram=gram)
                 grads[5 * l], grads[5 * l + 1], grads[5 * l + 2] = dw, dgamma, dbeta
                 continue
             K, Kpad, C = wt.shape[0], z.shape[-1], a.shape[-1]

@@ -63,6 +63,7 @@ def lib():
         L.sf_conv_k1_fwd_workspace_bytes.restype = ctypes.c_size_t
         L.sf_enc1_bwd_workspace_bytes.restype = ctypes.c_size_t
         L.sf_enc1_codes_bytes.restype = ctypes.c_size_t
+        L.sf_enc1_gram_workspace_bytes.restype = ctypes.c_size_t
         L.sf_date_image_metrics_workspace_bytes.restype = ctypes.c_size_t
         L.sf_gru_save_floats.restype = ctypes.c_size_t
         L.sf_attn_save_floats.restype = ctypes.c_size_t
@@ -73,7 +74,7 @@ def lib():
 EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_tile_shape", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nchw_to_nhwc_checked", "sf_nchw_bf16_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_bn_relu_avgpool_fwd_moments", "sf_bn_bwd_reduce_pooled", "sf_channel_sum", "sf_colsum_f32",
-           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_codes_bytes", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
+           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_codes_bytes", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_gram", "sf_enc1_gram_workspace_bytes", "sf_enc1_stats_gram", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
            "sf_conv_k1_fwd", "sf_conv_k1_fwd_ws", "sf_conv_k1_fwd_workspace_bytes", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss", "sf_image_station_loss_fwd", "sf_image_station_loss_bwd", "sf_image_station_loss_static",
@@ -684,19 +685,40 @@ def enc1_fwd(x, wp, st, K, want_codes: bool = False):
     return (y, codes) if want_codes else y
 
 
-def enc1_bwd(x, wp, dy, st, training, K, Creal, codes=None):
+ENC1_GRAM_DOUBLES = 6400  # SF_ENC1_GRAM_DOUBLES of include/sfhip.h
+
+
+def enc1_gram(x, Creal):
+    """Gram record of the layer's input (sf_enc1_gram): f64 [ENC1_GRAM_DOUBLES]; Creal <= 10."""
+    _dev(x)
+    N, H, W, _ = x.shape
+    rec = torch.empty(ENC1_GRAM_DOUBLES, device=x.device, dtype=torch.float64)
+    nbytes = int(lib().sf_enc1_gram_workspace_bytes(N, H, W, Creal))
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    _check(lib().sf_enc1_gram(_p(x), N, H, W, Creal, _p(rec), _p(ws), ctypes.c_size_t(nbytes), _stream()), "sf_enc1_gram")
+    return rec
+
+
+def enc1_stats_gram(wp, rec, K, Creal, ws):
+    """BatchNorm sums of the conv output from the Gram record (no pass over the conv output)."""
+    _dev(wp, rec, ws, dtypes=[torch.bfloat16, torch.float64, torch.float64])
+    _check(lib().sf_enc1_stats_gram(_p(wp), _p(rec), K, Creal, _p(ws), _stream()), "sf_enc1_stats_gram")
+
+
+def enc1_bwd(x, wp, dy, st, training, K, Creal, codes=None, gram=None):
     """(dw [K,Creal,3,3], dgamma, dbeta) of the fused first encoder layer; st = bn_finalize rows;
-    codes = what enc1_fwd(..., want_codes=True) returned for the same inputs, or None."""
-    _dev(x, wp, dy, st, codes)
+    codes = what enc1_fwd(..., want_codes=True) returned for the same inputs, or None; gram = the
+    record of enc1_gram for the same x, or None (then the routed backward accumulates it itself)."""
+    _dev(x, wp, dy, st, codes, gram)
     N, H, W, _ = x.shape
     nbytes = int(lib().sf_enc1_bwd_workspace_bytes(N, H, W, K, Creal))
     ws = torch.empty((nbytes + 7) // 8, device=x.device, dtype=torch.float64)      # 8-byte aligned
     dw = torch.empty((K, Creal, 3, 3), device=x.device, dtype=torch.float32)
     dgamma = torch.empty(K, device=x.device, dtype=torch.float32)
     dbeta = torch.empty(K, device=x.device, dtype=torch.float32)
-    _check(lib().sf_enc1_bwd(_p(x), _p(wp), _p(dy), _p(codes), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), int(training),
-                             _p(dw), _p(dgamma), _p(dbeta), _p(ws), ctypes.c_size_t(nbytes), N, H, W, K, Creal, _stream()),
-           "sf_enc1_bwd")
+    _check(lib().sf_enc1_bwd(_p(x), _p(wp), _p(dy), _p(codes), _p(gram), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
+                             int(training), _p(dw), _p(dgamma), _p(dbeta), _p(ws), ctypes.c_size_t(nbytes), N, H, W, K, Creal,
+                             _stream()), "sf_enc1_bwd")
     return dw, dgamma, dbeta
 
 

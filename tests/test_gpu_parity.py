@@ -681,6 +681,17 @@ def test_enc1_fused_layer_against_separate_kernels(sf):
         close(dbeta2, dbeta_ref.cpu().numpy(), 2e-3)
         close(dgamma2, dgamma_ref.cpu().numpy(), 5e-3)    # (the reference side sums dzm * z with z rounded to bf16, this side does not)
         close(dw2, dw_ref.cpu().numpy(), 2e-2)
+        if Cin <= 10:
+            # with the Gram record made beforehand (the training forward makes it for the statistics):
+            # the same sums, folded in the same order
+            rec = ops.enc1_gram(x, Cin)
+            dw3, dgamma3, dbeta3 = ops.enc1_bwd(x, wp, dy, st, training, K, Cin, codes=codes, gram=rec)
+            assert torch.equal(dw3, dw2) and torch.equal(dgamma3, dgamma2) and torch.equal(dbeta3, dbeta2)
+            # BatchNorm sums from the record against those of the stored (bf16-rounded) conv output
+            ws_g = torch.empty(2 * K, device=DEV, dtype=torch.float64)
+            ops.enc1_stats_gram(wp, rec, K, Cin, ws_g)
+            assert float((ws_g[K:] - ws_ref[K:]).abs().max() / ws_ref[K:].abs().max()) < 2e-4
+            assert float((ws_g[:K] - ws_ref[:K]).abs().max() / (ws_ref[K:].abs().max() * M) ** 0.5) < 2e-3
         close(dbeta2, dbeta.cpu().numpy(), 1e-5)
         close(dgamma2, dgamma.cpu().numpy(), 5e-3)        # (sum dzm * z over few hundred windows per channel, z with / without its bf16 rounding)
         close(dw2, dw.cpu().numpy(), 1e-2)
