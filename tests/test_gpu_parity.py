@@ -690,7 +690,7 @@ def test_enc1_fused_layer_against_separate_kernels(sf):
             # BatchNorm sums from the record against those of the stored (bf16-rounded) conv output
             ws_g = torch.empty(2 * K, device=DEV, dtype=torch.float64)
             ops.enc1_stats_gram(wp, rec, K, Cin, ws_g)
-            assert float((ws_g[K:] - ws_ref[K:]).abs().max() / ws_ref[K:].abs().max()) < 2e-4
+            assert float((ws_g[K:] - ws_ref[K:]).abs().max() / ws_ref[K:].abs().max()) < 1e-3       # (z unrounded here, bf16 there)
             assert float((ws_g[:K] - ws_ref[:K]).abs().max() / (ws_ref[K:].abs().max() * M) ** 0.5) < 2e-3
         close(dbeta2, dbeta.cpu().numpy(), 1e-5)
         close(dgamma2, dgamma.cpu().numpy(), 5e-3)        # (sum dzm * z over few hundred windows per channel, z with / without its bf16 rounding)
