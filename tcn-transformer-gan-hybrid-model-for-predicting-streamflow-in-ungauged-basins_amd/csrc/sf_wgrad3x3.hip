@@ -534,6 +534,215 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 4x4 stride 2 on the same scheme.  A workgroup owns 128 output channels x 64 input channels x the
+// EIGHT taps of one filter-row parity (rows ty = rp and rp + 2, all four columns): those taps read
+// input rows of one parity only, so the patch of a TH x TW tile is (TH + 1) rows of 2 TW + 2 pixels,
+// and per tile pixel the workgroup fetches 256 B of dOut and about 310 B of input for 131 KFLOP
+// (4.3 B per KFLOP, the 3x3 kernel's ratio; all sixteen taps on a 64 x 64 block cost 5.9).
+// LDS image of a buffer: [dOut k-quarter 0..3][In c-half 0][In c-half 1], dense 64-byte rows as
+// above.  A patch row is stored as its even columns followed by its odd columns (the copy's lanes
+// pick their pixels, so this costs nothing): tap column tx of output pixel lx is entry
+// lx + (tx >> 1) of plane tx & 1, consecutive output pixels read consecutive rows, and a tap is
+// again a constant byte offset.  Waves = (k-quarter pair, c half) x (row ty = rp / rp + 2): two dOut
+// fragments and four input fragments feed eight MFMAs per reduction step.
+// The buffers form a ring of NB: the copies of tile m + NB - 1 start when tile m is computed, so a
+// tile has NB - 1 tile times to land and the memory pipe never runs empty at a barrier; a wave waits
+// for its own copies of tile m only (a counted vmcnt: the copies of the later tiles stay in flight).
+// Every wave issues the same number of copies per tile, tiles past the end as zero fills that fetch
+// nothing, which keeps that count exact.
+template <int TP_, int PP_, int NB_> struct S2W {
+    static constexpr int TP = TP_, PP = PP_, NB = NB_;
+    static constexpr int DQ = TP * 64, XH = PP * 64;
+    static constexpr int BUF = 4 * DQ + 2 * XH;
+    static constexpr int NSTEPS = TP / 16;
+    static constexpr int ND = 4 * TP / 16, NX = 2 * PP / 16;     // copy jobs (1 KB each) per tile
+    static constexpr int J = (ND + NX) / 8;                        // per wave
+    static_assert((ND + NX) % 8 == 0, "copy jobs must divide over the eight waves");
+    static_assert(NB * BUF <= 160 * 1024, "ring exceeds LDS");
+};
+
+template <class G>
+__global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
+    constexpr int NB = G::NB, J = G::J;
+    extern __shared__ __attribute__((aligned(16))) char smw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kp = wave & 1, cb = (wave >> 1) & 1, grp = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int qq4 = (lane & 15) >> 2, csel = (lane >> 4) & 1, p4 = lane & 3;
+
+    // blocks = (row parity, k tile, c tile); the workgroups of one slice share their tiles and get
+    // ids that are equal modulo 8 (one XCD, one L2)
+    const int blocks = 2 * p.kt_tiles * p.ct_tiles;
+    int blk, slice;
+    if ((p.nslices & 7) == 0) {
+        const int j = blockIdx.x >> 3;
+        blk = j % blocks;
+        slice = (blockIdx.x & 7) + 8 * (j / blocks);
+    } else {
+        blk = blockIdx.x % blocks;
+        slice = blockIdx.x / blocks;
+    }
+    const int rp = blk & 1;
+    const int ct = (blk >> 1) % p.ct_tiles, kt = (blk >> 1) / p.ct_tiles;
+    const int PWh = p.TW + 1, PW = 2 * PWh, PH = p.TH + 1;
+    const int PP = PH * PW, TP = p.TH * p.TW;
+
+    // ---- copy jobs of this wave (tile-invariant part).  Job j = wave + 8 i: the first ND jobs fill
+    // dOut (quarter j & 3, row group j >> 2), the others the input (half, row group).
+    const int jrow = lane >> 2, jch = (lane & 3) * 8;
+    int j_pyx[J], j_rel[J], j_dst[J];
+    bool j_isx[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        const int j = wave + 8 * i;
+        j_isx[i] = j >= G::ND;
+        if (!j_isx[i]) {
+            const int dq = j & 3, g = j >> 2;
+            const int pix = 16 * g + jrow;
+            const int ly = pix / p.TW, lx = pix - ly * p.TW;
+            const bool ok = pix < TP && kt * 128 + dq * 32 + jch < p.Kd;
+            j_pyx[i] = ok ? ((ly << 16) | lx) : -1;
+            j_rel[i] = ((ly * p.OW + lx) * p.Kd + kt * 128 + dq * 32 + jch) * 2;          // bytes
+            j_dst[i] = dq * G::DQ + g * 1024;
+        } else {
+            const int jj = j - G::ND, xh = jj & 1, g = jj >> 1;
+            const int pp = 16 * g + jrow;
+            const int py = pp / PW, c = pp - py * PW;
+            const int plane = c >= PWh, px = 2 * (c - plane * PWh) + plane;              // column of the patch
+            const bool ok = pp < PP && ct * 64 + xh * 32 + jch < p.Cx;
+            j_pyx[i] = ok ? ((py << 16) | px) : -1;
+            j_rel[i] = ((2 * py * p.IW + px) * p.Cx + ct * 64 + xh * 32 + jch) * 2;       // bytes
+            j_dst[i] = 4 * G::DQ + xh * G::XH + g * 1024;
+        }
+    }
+
+    auto issue_tile = [&](int tile, char* lbase) __attribute__((always_inline)) {
+        const bool live = tile < p.ntiles;
+        if (!live) tile = 0;
+        const int txi = tile % p.tiles_x;
+        const int rest = tile / p.tiles_x;
+        const int tyi = rest % p.tiles_y;
+        const int n = rest / p.tiles_y;
+        const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
+        const int iy0 = 2 * oy0 + rp - 1, ix0 = 2 * ox0 - 1;
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.dout + (size_t)n * p.OH * p.OW * p.Kd), 0, (unsigned)(p.OH * p.OW * p.Kd * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.x + (size_t)n * p.IH * p.IW * p.Cx), 0, (unsigned)(p.IH * p.IW * p.Cx * 2), 0x00020000);
+        const int doff = (oy0 * p.OW + ox0) * p.Kd * 2;
+        const int xoff = (iy0 * p.IW + ix0) * p.Cx * 2;
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+            const int a = j_pyx[i] >> 16, b = j_pyx[i] & 0xffff;
+            if (!j_isx[i]) {
+                const bool ok = live && j_pyx[i] >= 0 && oy0 + a < p.OH && ox0 + b < p.OW;
+                const int voff = ok ? doff + j_rel[i] : (int)0x80000000;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lptr_t)(lbase + j_dst[i]), 16, voff, 0, 0, 0);
+            } else {
+                const int gy = iy0 + 2 * a, gx = ix0 + b;
+                const bool ok = live && j_pyx[i] >= 0 && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW;
+                const int voff = ok ? xoff + j_rel[i] : (int)0x80000000;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(lbase + j_dst[i]), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+
+    // byte offsets of this wave's four taps (filter row rp + 2 grp, columns 0..3)
+    int toffB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) toffB[j] = (grp * PW + (j & 1) * PWh + (j >> 1)) * 64;
+    int ppk[G::NSTEPS];
+#pragma unroll
+    for (int s = 0; s < G::NSTEPS; ++s) {
+        const int q0 = 16 * s + 8 * h + qq4, q1 = q0 + 4;
+        const int ly0 = q0 / p.TW, lx0 = q0 - ly0 * p.TW;
+        const int ly1 = q1 / p.TW, lx1 = q1 - ly1 * p.TW;
+        const int pp0 = q0 < TP ? ly0 * PW + lx0 : 0;
+        const int pp1 = q1 < TP ? ly1 * PW + lx1 : 0;
+        ppk[s] = (pp0 * 4) | ((pp1 * 4) << 16);
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][j][e] = 0.f;
+
+    const int lane_col = csel * 32 + p4 * 8;
+    const int aOff = 2 * kp * G::DQ + (8 * h + qq4) * 64 + lane_col;
+    const int bOff = 4 * G::DQ + cb * G::XH + lane_col;
+
+    // Positions (step, tap): the reads of position i + 2 are issued before the two MFMAs of position i
+    auto run_steps = [&](const char* aLane, const char* bBase) __attribute__((always_inline)) {
+        constexpr int TOT = G::NSTEPS * 4, DEPTH = 2;
+        bf16x8 fa0[2], fa1[2], fb[DEPTH + 1];
+        const char* b0[2];
+        const char* b1[2];
+        auto issue = [&](int i) {
+            const int s = i / 4, j = i % 4;
+            if (j == 0) {
+                int pk = ppk[s];
+                asm volatile("" : "+v"(pk));
+                b0[s & 1] = bBase + ((pk & 0xffff) << 4);
+                b1[s & 1] = bBase + ((pk >> 16) << 4);
+                fa0[s & 1] = tr_pair(aLane + s * 1024, aLane + s * 1024 + 256);
+                fa1[s & 1] = tr_pair(aLane + G::DQ + s * 1024, aLane + G::DQ + s * 1024 + 256);
+            }
+            fb[i % (DEPTH + 1)] = tr_pair(b0[s & 1] + toffB[j], b1[s & 1] + toffB[j]);
+        };
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) issue(i);
+#pragma unroll
+        for (int i = 0; i < TOT; ++i) {
+            if (i + DEPTH < TOT) issue(i + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][i % 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[(i / 4) & 1], fb[i % (DEPTH + 1)], acc[0][i % 4], 0, 0, 0);
+            acc[1][i % 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[(i / 4) & 1], fb[i % (DEPTH + 1)], acc[1][i % 4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const bool wave_idle = kt * 128 + 2 * kp * 32 >= p.Kd || ct * 64 + cb * 32 >= p.Cx;
+    const int tile_step = p.nslices;
+    // one tile: its copies have landed in `cur` (own count, then the barrier, which also says that
+    // every wave is done with the buffer `fill`); start the copies NB - 1 tiles ahead, compute
+    auto phase = [&](const char* __restrict__ cur, char* __restrict__ fill, int tile) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NB - 2) * J) : "memory");
+        issue_tile(tile + (NB - 1) * tile_step, fill);
+        if (!wave_idle) run_steps(cur + aOff, cur + bOff);
+    };
+#pragma unroll
+    for (int m = 0; m < NB - 1; ++m) issue_tile(slice + m * tile_step, smw + m * G::BUF);
+    for (int tile = slice; tile < p.ntiles;) {
+#pragma unroll
+        for (int ph = 0; ph < NB; ++ph) {
+            phase(smw + ph * G::BUF, smw + ((ph + NB - 1) % NB) * G::BUF, tile);
+            tile += tile_step;
+            if (tile >= p.ntiles) break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero fills of the tail
+
+    // ---- slab store: ws[slice][k][t][c]
+    float* slab = p.ws + (size_t)slice * p.K64 * 16 * p.C64;
+    const int c = ct * 64 + cb * 32 + r;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = (rp + 2 * grp) * 4 + j;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = kt * 128 + (2 * kp + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                slab[((size_t)k * 16 + t) * p.C64 + c] = acc[a][j][e];
+            }
+        }
+}
+
 // dw[k][c][t] (OIHW f32) = sum_slabs ws[slab][k][t][c]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslabs, int K64,
                                     int C64, int K, int Cin, int taps) {
@@ -693,6 +902,89 @@ int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t
     return SF_OK;
 }
 
+// tile of the stride-2 DMA kernel: at most G::TP pixels, patch (th + 1) x (2 tw + 2) at most G::PP
+template <class G> void pick_tile_s2w(int OH, int OW, int* th, int* tw) {
+    long long best = -1;
+    int bth = 1, btw = 4, bpp = 0;
+    for (int w = 4; w <= G::TP; ++w) {
+        int hh = G::TP / w;
+        if (hh > OH) hh = OH;
+        while (hh >= 1 && (hh + 1) * (2 * w + 2) > G::PP) --hh;
+        if (hh < 1) continue;
+        const int pp = (hh + 1) * (2 * w + 2);
+        const long long tiles = (long long)((OW + w - 1) / w) * ((OH + hh - 1) / hh);
+        if (best < 0 || tiles < best || (tiles == best && pp < bpp)) { best = tiles; bth = hh; btw = w; bpp = pp; }
+    }
+    *th = bth; *tw = btw;
+}
+
+int slices_for_s2(int K, int Cin) {
+    const int blocks = 2 * ((K + 127) / 128) * ((Cin + 63) / 64);
+    int n = 256 / blocks;
+    return n < 1 ? 1 : n;
+}
+
+template <class G>
+int run_wgrad4s2_dma(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, size_t need, int N,
+                     int IH, int IW, int OH, int OW, int Cx, int Kd, int K, int Cin, hipStream_t s) {
+    const char* who = "sf_wgrad4x4s2";
+    if (ws_bytes < need) { sf_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need); return SF_EINVAL; }
+    WPParams p;
+    p.dout = (const bf16*)dout; p.x = (const bf16*)x; p.ws = ws;
+    p.N = N; p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW; p.Kd = Kd; p.Cx = Cx;
+    pick_tile_s2w<G>(OH, OW, &p.TH, &p.TW);
+    p.tiles_x = (OW + p.TW - 1) / p.TW;
+    p.tiles_y = (OH + p.TH - 1) / p.TH;
+    const long long ntiles = (long long)N * p.tiles_x * p.tiles_y;
+    if (ntiles >= 0x7fffffffLL / 2) { sf_set_error("%s: too many tiles", who); return SF_EINVAL; }
+    // 32-bit byte offsets inside one image (a tile's last patch row may lie one row pair below it)
+    if (2LL * (IH + 4) * IW * Cx >= 0x7fffffffLL || 2LL * (OH + 1) * OW * Kd >= 0x7fffffffLL) {
+        sf_set_error("%s: one image exceeds 2 GiB", who); return SF_EINVAL;
+    }
+    p.ntiles = (int)ntiles;
+    p.kt_tiles = (K + 127) / 128;
+    p.ct_tiles = (Cin + 63) / 64;
+    p.K64 = p.kt_tiles * 128;
+    p.C64 = p.ct_tiles * 64;
+    int nslices = slices_for_s2(K, Cin);
+    p.nslices = nslices;
+    p.tiles_per_slice = 0;
+    p.qslot = -1; p.shirk = 0;
+    const size_t lds = (size_t)G::NB * G::BUF;
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad4s2_dma_kernel<G>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            sf_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", who, lds);
+            return SF_ELAUNCH;
+        }
+        attr_set.mark();
+    }
+    const int blocks = 2 * p.kt_tiles * p.ct_tiles;
+    hipLaunchKernelGGL(wgrad4s2_dma_kernel<G>, dim3((unsigned)(nslices * blocks)), dim3(NTW), lds, s, p);
+    const long long total = (long long)K * 16 * Cin;
+    int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, ws, dw, nslices, p.K64, p.C64, K, Cin, 16);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sf_set_error("%s: launch failed: %s", who, hipGetErrorString(e)); return SF_ELAUNCH; }
+    return SF_OK;
+}
+
+// Ring depth of the stride-2 kernel: SF_WGRAD4_RING = 2 (128-pixel tiles, the default), 3 (80) or 4 (64).
+// Measured at the PatchGAN's three layers, batch 32, launch + slab fold: 102 / 101 / 113 us with 2 buffers,
+// 99 / 105 / 121 with 3, 107 / 111 / 127 with 4: a longer landing window buys nothing (the copies are
+// bandwidth-bound, not latency-bound) and the smaller tiles fit the maps worse.
+int wgrad4_ring() {
+    static const int v = [] { const char* e = getenv("SF_WGRAD4_RING"); const int n = e ? atoi(e) : 2; return n < 2 || n > 4 ? 2 : n; }();
+    return v;
+}
+
+// SF_WGRAD4_OLD=1 keeps the register-staged kernel (sixteen taps on 64 x 64 blocks) for comparisons
+bool wgrad4_old() {
+    static const bool v = [] { const char* e = getenv("SF_WGRAD4_OLD"); return e && e[0] == '1'; }();
+    return v;
+}
+
 }  // namespace
 
 extern "C" int sf_set_wgrad_scheduling(int dynamic) {
@@ -707,6 +999,8 @@ extern "C" size_t sf_wgrad3x3_workspace_bytes(int N, int H, int W, int K, int Ci
 
 extern "C" size_t sf_wgrad4x4s2_workspace_bytes(int N, int IH, int IW, int K, int Cin) {
     (void)N; (void)IH; (void)IW;
+    if (!wgrad4_old())
+        return sizeof(float) * (size_t)slices_for_s2(K, Cin) * ((K + 127) / 128 * 128) * 16 * ((Cin + 63) / 64 * 64);
     return sizeof(float) * (size_t)slices_for(K, Cin) * ((K + 63) / 64 * 64) * 16 * ((Cin + 63) / 64 * 64);
 }
 
@@ -731,6 +1025,16 @@ extern "C" int sf_wgrad4x4s2(const void* x, const void* dout, float* dw, float* 
     if (int rc = wgrad_common_checks("sf_wgrad4x4s2", x, dout, dw, ws, N, IH, IW, Cx, Kd, K, Cin)) return rc;
     SF_REQUIRE(IH >= 2 && IW >= 2, "sf_wgrad4x4s2: input smaller than the filter footprint");
     const int OH = (IH - 2) / 2 + 1, OW = (IW - 2) / 2 + 1;
+    if (!wgrad4_old())
+    {
+        const size_t need = sf_wgrad4x4s2_workspace_bytes(N, IH, IW, K, Cin);
+        hipStream_t s = (hipStream_t)stream;
+        switch (wgrad4_ring()) {
+        case 3: return run_wgrad4s2_dma<S2W<80, 224, 3>>(x, dout, dw, ws, ws_bytes, need, N, IH, IW, OH, OW, Cx, Kd, K, Cin, s);
+        case 4: return run_wgrad4s2_dma<S2W<64, 192, 4>>(x, dout, dw, ws, ws_bytes, need, N, IH, IW, OH, OW, Cx, Kd, K, Cin, s);
+        default: return run_wgrad4s2_dma<S2W<128, 320, 2>>(x, dout, dw, ws, ws_bytes, need, N, IH, IW, OH, OW, Cx, Kd, K, Cin, s);
+        }
+    }
     return run_wgrad<16, 2>(x, dout, dw, ws, ws_bytes, sf_wgrad4x4s2_workspace_bytes(N, IH, IW, K, Cin), N, IH, IW, OH,
                             OW, Cx, Kd, K, Cin, (hipStream_t)stream, "sf_wgrad4x4s2");
 }
