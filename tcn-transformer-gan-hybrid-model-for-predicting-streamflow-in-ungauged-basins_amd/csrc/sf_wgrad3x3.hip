@@ -535,46 +535,69 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// 4x4 stride 2 on the same scheme.  A workgroup owns 128 output channels x 64 input channels x the
-// EIGHT taps of one filter-row parity (rows ty = rp and rp + 2, all four columns): those taps read
-// input rows of one parity only, so the patch of a TH x TW tile is (TH + 1) rows of 2 TW + 2 pixels,
-// and per tile pixel the workgroup fetches 256 B of dOut and about 310 B of input for 131 KFLOP
-// (4.3 B per KFLOP, the 3x3 kernel's ratio; all sixteen taps on a 64 x 64 block cost 5.9).
-// LDS image of a buffer: [dOut k-quarter 0..3][In c-half 0][In c-half 1], dense 64-byte rows as
-// above.  A patch row is stored as its even columns followed by its odd columns (the copy's lanes
-// pick their pixels, so this costs nothing): tap column tx of output pixel lx is entry
-// lx + (tx >> 1) of plane tx & 1, consecutive output pixels read consecutive rows, and a tap is
-// again a constant byte offset.  Waves = (k-quarter pair, c half) x (row ty = rp / rp + 2): two dOut
-// fragments and four input fragments feed eight MFMAs per reduction step.
-// The buffers form a ring of NB: the copies of tile m + NB - 1 start when tile m is computed, so a
-// tile has NB - 1 tile times to land and the memory pipe never runs empty at a barrier; a wave waits
-// for its own copies of tile m only (a counted vmcnt: the copies of the later tiles stay in flight).
-// Every wave issues the same number of copies per tile, tiles past the end as zero fills that fetch
-// nothing, which keeps that count exact.
-template <int TP_, int PP_, int NB_> struct S2W {
+// Blocks of 128 output channels x 64 input channels on the same scheme (wgrad_wide_kernel), for
+// layers with more than 64 output channels: per tile pixel a workgroup fetches 256 B of dOut and
+// the patch's share of 128 B of input, for twice the FLOP of a 64 x 64 block.
+//   3x3 stride 1: all nine taps; waves = (k quarter, c half), nine accumulator tiles each: one dOut
+//     fragment and nine input fragments feed nine MFMAs per reduction step (3.0 B per KFLOP against
+//     3.9 for the 64 x 64 blocks, and the input is fetched once instead of once per 64 channels).
+//   4x4 stride 2: the EIGHT taps of one filter-row parity (rows ty = rp and rp + 2, all four
+//     columns).  Those taps read input rows of one parity only, so the patch of a TH x TW tile is
+//     (TH + 1) rows of 2 TW + 2 pixels: 4.3 B per KFLOP (all sixteen taps on a 64 x 64 block: 5.9).
+//     A patch row is stored as its even columns followed by its odd columns (the copy's lanes pick
+//     their pixels, so this costs nothing): tap column tx of output pixel lx is entry lx + (tx >> 1)
+//     of plane tx & 1, consecutive output pixels read consecutive rows, and a tap is again a
+//     constant byte offset.  Waves = (k-quarter pair, c half) x (row ty = rp / rp + 2): two dOut
+//     fragments and four input fragments feed eight MFMAs per reduction step.
+// LDS image of a buffer: [dOut k-quarter 0..3][In c-half 0][In c-half 1], dense 64-byte rows as above.
+// The buffers form a ring of NB: the copies of tile m + NB - 1 start when tile m is computed, and a
+// wave waits for its own copies of tile m only (a counted vmcnt: the copies of the later tiles stay
+// in flight).  Every wave issues the same number of copies per tile, tiles past the end as zero
+// fills that fetch nothing, which keeps that count exact.
+#ifndef SF_WIDE_DEPTH
+#define SF_WIDE_DEPTH 2         // fragment reads in flight ahead of the MFMA that consumes them
+#endif
+template <bool S2_, int TP_, int PP_, int NB_> struct WideCfg {
+    static constexpr bool S2 = S2_;
     static constexpr int TP = TP_, PP = PP_, NB = NB_;
+    static constexpr int TAPS = S2 ? 16 : 9;
+    static constexpr int NA = S2 ? 2 : 1, NT = S2 ? 4 : 9;        // dOut fragments and taps per wave
     static constexpr int DQ = TP * 64, XH = PP * 64;
     static constexpr int BUF = 4 * DQ + 2 * XH;
     static constexpr int NSTEPS = TP / 16;
     static constexpr int ND = 4 * TP / 16, NX = 2 * PP / 16;     // copy jobs (1 KB each) per tile
     static constexpr int J = (ND + NX) / 8;                        // per wave
     static_assert((ND + NX) % 8 == 0, "copy jobs must divide over the eight waves");
-    static_assert(NB * BUF <= 160 * 1024, "ring exceeds LDS");
+    static_assert(NB * BUF + 16 <= 160 * 1024, "ring exceeds LDS");
+    static_assert((NB - 1) * J < 64, "vmcnt counts 63 at most");
 };
 
-template <class G>
-__global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
-    constexpr int NB = G::NB, J = G::J;
+// Tiles of the wide kernel when other kernels share the CUs (sf_set_wgrad_scheduling): the
+// workgroups of one XCD and block draw their tiles from one list (positions x + 8 m of the launch's
+// tile order) instead of streaming fixed slices, so a workgroup that starts late leaves its share to
+// the others.  Thread 0 asks for the tile two phases ahead while the current one is computed and parks
+// the answer in LDS before the next barrier.
+__device__ WorkQueue g_widequeues[SF_QUEUE_SLOTS];
+StreamSlots g_wideslots;
+
+template <class G, bool QUEUE>
+__global__ __launch_bounds__(NTW, 2) void wgrad_wide_kernel(WPParams p) {
+    static_assert(!QUEUE || G::NB == 2, "the tile queue assumes two buffers");
+    constexpr int NB = G::NB, J = G::J, NA = G::NA, NT = G::NT;
+    constexpr bool S2 = G::S2;
     extern __shared__ __attribute__((aligned(16))) char smw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kp = wave & 1, cb = (wave >> 1) & 1, grp = wave >> 2;
+    // S2: wave = (k-quarter pair, c half, filter row of the parity); S1: wave = (k quarter, c half)
+    const int kq0 = S2 ? 2 * (wave & 1) : (wave & 3);
+    const int cb = S2 ? (wave >> 1) & 1 : wave >> 2;
+    const int grp = S2 ? wave >> 2 : 0;
     const int r = lane & 31, h = lane >> 5;
     const int qq4 = (lane & 15) >> 2, csel = (lane >> 4) & 1, p4 = lane & 3;
 
-    // blocks = (row parity, k tile, c tile); the workgroups of one slice share their tiles and get
-    // ids that are equal modulo 8 (one XCD, one L2)
-    const int blocks = 2 * p.kt_tiles * p.ct_tiles;
+    // blocks = (k tile, c tile) [x row parity]; the workgroups of one slice share their tiles and
+    // get ids that are equal modulo 8 (one XCD, one L2)
+    const int blocks = (S2 ? 2 : 1) * p.kt_tiles * p.ct_tiles;
     int blk, slice;
     if ((p.nslices & 7) == 0) {
         const int j = blockIdx.x >> 3;
@@ -584,10 +607,13 @@ __global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
         blk = blockIdx.x % blocks;
         slice = blockIdx.x / blocks;
     }
-    const int rp = blk & 1;
-    const int ct = (blk >> 1) % p.ct_tiles, kt = (blk >> 1) / p.ct_tiles;
-    const int PWh = p.TW + 1, PW = 2 * PWh, PH = p.TH + 1;
+    const int head = (blockIdx.x & 7) + 8 * blk;      // tile list of this XCD and block
+    const int rp = S2 ? blk & 1 : 0;
+    if (S2) blk >>= 1;
+    const int ct = blk % p.ct_tiles, kt = blk / p.ct_tiles;
+    const int PWh = p.TW + 1, PW = S2 ? 2 * PWh : p.TW + 2, PH = S2 ? p.TH + 1 : p.TH + 2;
     const int PP = PH * PW, TP = p.TH * p.TW;
+    constexpr int RM = S2 ? 2 : 1;          // input rows between two patch rows
 
     // ---- copy jobs of this wave (tile-invariant part).  Job j = wave + 8 i: the first ND jobs fill
     // dOut (quarter j & 3, row group j >> 2), the others the input (half, row group).
@@ -610,10 +636,11 @@ __global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
             const int jj = j - G::ND, xh = jj & 1, g = jj >> 1;
             const int pp = 16 * g + jrow;
             const int py = pp / PW, c = pp - py * PW;
-            const int plane = c >= PWh, px = 2 * (c - plane * PWh) + plane;              // column of the patch
+            int px = c;                                                                   // column of the patch
+            if (S2) { const int plane = c >= PWh; px = 2 * (c - plane * PWh) + plane; }
             const bool ok = pp < PP && ct * 64 + xh * 32 + jch < p.Cx;
             j_pyx[i] = ok ? ((py << 16) | px) : -1;
-            j_rel[i] = ((2 * py * p.IW + px) * p.Cx + ct * 64 + xh * 32 + jch) * 2;       // bytes
+            j_rel[i] = ((RM * py * p.IW + px) * p.Cx + ct * 64 + xh * 32 + jch) * 2;      // bytes
             j_dst[i] = 4 * G::DQ + xh * G::XH + g * 1024;
         }
     }
@@ -626,7 +653,7 @@ __global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
         const int tyi = rest % p.tiles_y;
         const int n = rest / p.tiles_y;
         const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
-        const int iy0 = 2 * oy0 + rp - 1, ix0 = 2 * ox0 - 1;
+        const int iy0 = S2 ? 2 * oy0 + rp - 1 : oy0 - 1, ix0 = S2 ? 2 * ox0 - 1 : ox0 - 1;
         const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.dout + (size_t)n * p.OH * p.OW * p.Kd), 0, (unsigned)(p.OH * p.OW * p.Kd * 2), 0x00020000);
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -641,7 +668,7 @@ __global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
                 const int voff = ok ? doff + j_rel[i] : (int)0x80000000;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lptr_t)(lbase + j_dst[i]), 16, voff, 0, 0, 0);
             } else {
-                const int gy = iy0 + 2 * a, gx = ix0 + b;
+                const int gy = iy0 + RM * a, gx = ix0 + b;
                 const bool ok = live && j_pyx[i] >= 0 && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW;
                 const int voff = ok ? xoff + j_rel[i] : (int)0x80000000;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(lbase + j_dst[i]), 16, voff, 0, 0, 0);
@@ -649,10 +676,10 @@ __global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
         }
     };
 
-    // byte offsets of this wave's four taps (filter row rp + 2 grp, columns 0..3)
-    int toffB[4];
+    // byte offsets of this wave's taps: S2 filter row rp + 2 grp, columns 0..3; S1 all nine
+    int toffB[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) toffB[j] = (grp * PW + (j & 1) * PWh + (j >> 1)) * 64;
+    for (int j = 0; j < NT; ++j) toffB[j] = S2 ? (grp * PW + (j & 1) * PWh + (j >> 1)) * 64 : ((j / 3) * PW + j % 3) * 64;
     int ppk[G::NSTEPS];
 #pragma unroll
     for (int s = 0; s < G::NSTEPS; ++s) {
@@ -664,33 +691,34 @@ __global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
         ppk[s] = (pp0 * 4) | ((pp1 * 4) << 16);
     }
 
-    f32x16 acc[2][4];
+    f32x16 acc[NA][NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][j][e] = 0.f;
 
     const int lane_col = csel * 32 + p4 * 8;
-    const int aOff = 2 * kp * G::DQ + (8 * h + qq4) * 64 + lane_col;
+    const int aOff = kq0 * G::DQ + (8 * h + qq4) * 64 + lane_col;
     const int bOff = 4 * G::DQ + cb * G::XH + lane_col;
 
-    // Positions (step, tap): the reads of position i + 2 are issued before the two MFMAs of position i
+    // Positions (step, tap): the reads of position i + 2 are issued before the MFMAs of position i
     auto run_steps = [&](const char* aLane, const char* bBase) __attribute__((always_inline)) {
-        constexpr int TOT = G::NSTEPS * 4, DEPTH = 2;
-        bf16x8 fa0[2], fa1[2], fb[DEPTH + 1];
+        constexpr int TOT = G::NSTEPS * NT, DEPTH = SF_WIDE_DEPTH;
+        bf16x8 fa[2][NA], fb[DEPTH + 1];
         const char* b0[2];
         const char* b1[2];
         auto issue = [&](int i) {
-            const int s = i / 4, j = i % 4;
+            const int s = i / NT, j = i % NT;
             if (j == 0) {
                 int pk = ppk[s];
                 asm volatile("" : "+v"(pk));
                 b0[s & 1] = bBase + ((pk & 0xffff) << 4);
                 b1[s & 1] = bBase + ((pk >> 16) << 4);
-                fa0[s & 1] = tr_pair(aLane + s * 1024, aLane + s * 1024 + 256);
-                fa1[s & 1] = tr_pair(aLane + G::DQ + s * 1024, aLane + G::DQ + s * 1024 + 256);
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    fa[s & 1][a] = tr_pair(aLane + a * G::DQ + s * 1024, aLane + a * G::DQ + s * 1024 + 256);
             }
             fb[i % (DEPTH + 1)] = tr_pair(b0[s & 1] + toffB[j], b1[s & 1] + toffB[j]);
         };
@@ -700,45 +728,88 @@ __global__ __launch_bounds__(NTW, 2) void wgrad4s2_dma_kernel(WPParams p) {
         for (int i = 0; i < TOT; ++i) {
             if (i + DEPTH < TOT) issue(i + DEPTH);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][i % 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[(i / 4) & 1], fb[i % (DEPTH + 1)], acc[0][i % 4], 0, 0, 0);
-            acc[1][i % 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[(i / 4) & 1], fb[i % (DEPTH + 1)], acc[1][i % 4], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                acc[a][i % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(i / NT) & 1][a], fb[i % (DEPTH + 1)], acc[a][i % NT], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    const bool wave_idle = kt * 128 + 2 * kp * 32 >= p.Kd || ct * 64 + cb * 32 >= p.Cx;
+    const bool wave_idle = kt * 128 + kq0 * 32 >= p.Kd || ct * 64 + cb * 32 >= p.Cx;
     const int tile_step = p.nslices;
     // one tile: its copies have landed in `cur` (own count, then the barrier, which also says that
     // every wave is done with the buffer `fill`); start the copies NB - 1 tiles ahead, compute
     auto phase = [&](const char* __restrict__ cur, char* __restrict__ fill, int tile) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NB - 2) * J) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NB - 2) * J) : "memory");
+#if defined(SF_WIDE_DIAG_NODMA)       // timing only: tiles past the first ring are zero fills
+        issue_tile(0x3fffffff, fill);
+#elif defined(SF_WIDE_DIAG_SAMETILE)    // timing only: every copy fetches the slice's first tile (L2 hits)
+        issue_tile(slice, fill);
+#else
         issue_tile(tile + (NB - 1) * tile_step, fill);
+#endif
+#ifndef SF_WIDE_DIAG_NOMFMA     // timing only: copies and barriers without the arithmetic
         if (!wave_idle) run_steps(cur + aOff, cur + bOff);
+#endif
     };
+    if constexpr (!QUEUE) {
 #pragma unroll
-    for (int m = 0; m < NB - 1; ++m) issue_tile(slice + m * tile_step, smw + m * G::BUF);
-    for (int tile = slice; tile < p.ntiles;) {
+        for (int m = 0; m < NB - 1; ++m) issue_tile(slice + m * tile_step, smw + m * G::BUF);
+        for (int tile = slice; tile < p.ntiles;) {
 #pragma unroll
-        for (int ph = 0; ph < NB; ++ph) {
-            phase(smw + ph * G::BUF, smw + ((ph + NB - 1) % NB) * G::BUF, tile);
-            tile += tile_step;
-            if (tile >= p.ntiles) break;
+            for (int ph = 0; ph < NB; ++ph) {
+                phase(smw + ph * G::BUF, smw + ((ph + NB - 1) % NB) * G::BUF, tile);
+                tile += tile_step;
+                if (tile >= p.ntiles) break;
+            }
         }
+    } else {
+        constexpr int DONE = 0x7fffffff;
+        WorkQueue* const wq = g_widequeues + p.qslot;
+        int* const s_next = reinterpret_cast<int*>(smw + NB * G::BUF);         // tile of phase k: slot k & 1
+        auto tile_at = [&](int m) {
+            const long long t = (blockIdx.x & 7) + 8LL * m;
+            return t < p.ntiles ? (int)t : DONE;
+        };
+        if (tid == 0) {
+            const int m0 = queue_take(wq, head), m1 = queue_take(wq, head);
+            s_next[0] = tile_at(m0);
+            s_next[1] = tile_at(m1);
+        }
+        __syncthreads();
+        int cur_tile = __builtin_amdgcn_readfirstlane(s_next[0]);
+        issue_tile(cur_tile, smw);
+        int pending = 0;
+        auto qphase = [&](int k, const char* __restrict__ cur, char* __restrict__ fill) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int next_tile = __builtin_amdgcn_readfirstlane(s_next[(k + 1) & 1]);
+            if (tid == 0) pending = queue_take_async(wq, head);             // the tile of phase k + 2
+            issue_tile(next_tile, fill);
+            if (!wave_idle) run_steps(cur + aOff, cur + bOff);
+            if (tid == 0) s_next[k & 1] = tile_at(queue_ticket_wait(pending));
+            cur_tile = next_tile;
+        };
+        while (cur_tile != DONE) {
+            qphase(0, smw, smw + G::BUF);
+            if (cur_tile == DONE) break;
+            qphase(1, smw + G::BUF, smw);
+        }
+        if (tid == 0) queue_leave(wq, 8 * blocks, gridDim.x);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero fills of the tail
 
     // ---- slab store: ws[slice][k][t][c]
-    float* slab = p.ws + (size_t)slice * p.K64 * 16 * p.C64;
+    float* slab = p.ws + (size_t)slice * p.K64 * G::TAPS * p.C64;
     const int c = ct * 64 + cb * 32 + r;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = (rp + 2 * grp) * 4 + j;
+        for (int j = 0; j < NT; ++j) {
+            const int t = S2 ? (rp + 2 * grp) * 4 + j : j;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int k = kt * 128 + (2 * kp + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                slab[((size_t)k * 16 + t) * p.C64 + c] = acc[a][j][e];
+                const int k = kt * 128 + (kq0 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                slab[((size_t)k * G::TAPS + t) * p.C64 + c] = acc[a][j][e];
             }
         }
 }
@@ -902,42 +973,43 @@ int run_wgrad3_dma(const void* x, const void* dout, float* dw, float* ws, size_t
     return SF_OK;
 }
 
-// tile of the stride-2 DMA kernel: at most G::TP pixels, patch (th + 1) x (2 tw + 2) at most G::PP
-template <class G> void pick_tile_s2w(int OH, int OW, int* th, int* tw) {
+// tile of the wide-block kernel: at most G::TP pixels, patch (th + 2) x (tw + 2) [stride 2: (th + 1) x
+// (2 tw + 2)] at most G::PP; fewest tiles, then least halo
+template <class G> void pick_tile_wide(int OH, int OW, int* th, int* tw) {
     long long best = -1;
     int bth = 1, btw = 4, bpp = 0;
+    auto patch = [](int hh, int w) { return G::S2 ? (hh + 1) * (2 * w + 2) : (hh + 2) * (w + 2); };
     for (int w = 4; w <= G::TP; ++w) {
         int hh = G::TP / w;
         if (hh > OH) hh = OH;
-        while (hh >= 1 && (hh + 1) * (2 * w + 2) > G::PP) --hh;
+        while (hh >= 1 && patch(hh, w) > G::PP) --hh;
         if (hh < 1) continue;
-        const int pp = (hh + 1) * (2 * w + 2);
+        const int pp = patch(hh, w);
         const long long tiles = (long long)((OW + w - 1) / w) * ((OH + hh - 1) / hh);
         if (best < 0 || tiles < best || (tiles == best && pp < bpp)) { best = tiles; bth = hh; btw = w; bpp = pp; }
     }
     *th = bth; *tw = btw;
 }
 
-int slices_for_s2(int K, int Cin) {
-    const int blocks = 2 * ((K + 127) / 128) * ((Cin + 63) / 64);
+int slices_for_wide(int K, int Cin, bool s2) {
+    const int blocks = (s2 ? 2 : 1) * ((K + 127) / 128) * ((Cin + 63) / 64);
     int n = 256 / blocks;
     return n < 1 ? 1 : n;
 }
 
 template <class G>
-int run_wgrad4s2_dma(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, size_t need, int N,
-                     int IH, int IW, int OH, int OW, int Cx, int Kd, int K, int Cin, hipStream_t s) {
-    const char* who = "sf_wgrad4x4s2";
+int run_wgrad_wide(const char* who, const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, size_t need,
+                   int N, int IH, int IW, int OH, int OW, int Cx, int Kd, int K, int Cin, hipStream_t s) {
     if (ws_bytes < need) { sf_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need); return SF_EINVAL; }
     WPParams p;
     p.dout = (const bf16*)dout; p.x = (const bf16*)x; p.ws = ws;
     p.N = N; p.IH = IH; p.IW = IW; p.OH = OH; p.OW = OW; p.Kd = Kd; p.Cx = Cx;
-    pick_tile_s2w<G>(OH, OW, &p.TH, &p.TW);
+    pick_tile_wide<G>(OH, OW, &p.TH, &p.TW);
     p.tiles_x = (OW + p.TW - 1) / p.TW;
     p.tiles_y = (OH + p.TH - 1) / p.TH;
     const long long ntiles = (long long)N * p.tiles_x * p.tiles_y;
     if (ntiles >= 0x7fffffffLL / 2) { sf_set_error("%s: too many tiles", who); return SF_EINVAL; }
-    // 32-bit byte offsets inside one image (a tile's last patch row may lie one row pair below it)
+    // 32-bit byte offsets inside one image (a tile's patch may reach a few rows past the image)
     if (2LL * (IH + 4) * IW * Cx >= 0x7fffffffLL || 2LL * (OH + 1) * OW * Kd >= 0x7fffffffLL) {
         sf_set_error("%s: one image exceeds 2 GiB", who); return SF_EINVAL;
     }
@@ -946,36 +1018,48 @@ int run_wgrad4s2_dma(const void* x, const void* dout, float* dw, float* ws, size
     p.ct_tiles = (Cin + 63) / 64;
     p.K64 = p.kt_tiles * 128;
     p.C64 = p.ct_tiles * 64;
-    int nslices = slices_for_s2(K, Cin);
+    int nslices = slices_for_wide(K, Cin, G::S2);
     p.nslices = nslices;
     p.tiles_per_slice = 0;
-    p.qslot = -1; p.shirk = 0;
-    const size_t lds = (size_t)G::NB * G::BUF;
+    const int blocks = (G::S2 ? 2 : 1) * p.kt_tiles * p.ct_tiles;
+    const bool queue_ok = G::NB == 2 && g_dynamic_tiles.load() && (nslices & 7) == 0 && 8 * blocks <= SF_QUEUE_HEADS &&
+                          p.ntiles > nslices;
+    p.qslot = queue_ok ? g_wideslots.slot_of(s) : -1;
+    p.shirk = 0;
+    const size_t lds = (size_t)G::NB * G::BUF + 16;
     static DeviceOnce attr_set;
     if (!attr_set.done()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad4s2_dma_kernel<G>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<G, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<G, G::NB == 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sf_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", who, lds);
             return SF_ELAUNCH;
         }
         attr_set.mark();
     }
-    const int blocks = 2 * p.kt_tiles * p.ct_tiles;
-    hipLaunchKernelGGL(wgrad4s2_dma_kernel<G>, dim3((unsigned)(nslices * blocks)), dim3(NTW), lds, s, p);
-    const long long total = (long long)K * 16 * Cin;
+    if (p.qslot >= 0) hipLaunchKernelGGL((wgrad_wide_kernel<G, G::NB == 2>), dim3((unsigned)(nslices * blocks)), dim3(NTW), lds, s, p);
+    else hipLaunchKernelGGL((wgrad_wide_kernel<G, false>), dim3((unsigned)(nslices * blocks)), dim3(NTW), lds, s, p);
+    const long long total = (long long)K * G::TAPS * Cin;
     int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, ws, dw, nslices, p.K64, p.C64, K, Cin, 16);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, ws, dw, nslices, p.K64, p.C64, K, Cin, G::TAPS);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sf_set_error("%s: launch failed: %s", who, hipGetErrorString(e)); return SF_ELAUNCH; }
     return SF_OK;
 }
 
-// Ring depth of the stride-2 kernel: SF_WGRAD4_RING = 2 (128-pixel tiles, the default), 3 (80) or 4 (64).
-// Measured at the PatchGAN's three layers, batch 32, launch + slab fold: 102 / 101 / 113 us with 2 buffers,
-// 99 / 105 / 121 with 3, 107 / 111 / 127 with 4: a longer landing window buys nothing (the copies are
-// bandwidth-bound, not latency-bound) and the smaller tiles fit the maps worse.
-int wgrad4_ring() {
-    static const int v = [] { const char* e = getenv("SF_WGRAD4_RING"); const int n = e ? atoi(e) : 2; return n < 2 || n > 4 ? 2 : n; }();
+// Measured (batch 32, launch + slab fold, probe data).  PatchGAN layers: 264 / 231 / 209 us on the
+// register-staged 64 x 64 kernel, 102 / 101 / 113 us here with two buffers of 128-pixel tiles; rings of
+// three 80-pixel or four 64-pixel buffers 99 / 105 / 121 and 107 / 111 / 127.  Encoder 3x3 layer (160 maps of
+// 200 x 200, 64 -> 128): 0.97 ms on 64 x 64 blocks, 0.85 ms here with two buffers of 160-pixel tiles, 0.87 with
+// 128-pixel tiles, three 96-pixel or four 64-pixel buffers.  So a longer landing window buys nothing and the
+// smaller tiles fit the maps worse; the ring stays at two.  With the copies taken out (SF_WIDE_DIAG_NODMA,
+// zero operands) the encoder launch takes 0.50 ms, with the MFMAs taken out (SF_WIDE_DIAG_NOMFMA) 0.43 ms
+// (6.5 TB/s), with every copy an L2 hit (SF_WIDE_DIAG_SAMETILE) 0.70 ms.
+
+// 3x3 layers with more than 64 output channels: SF_WGRAD3_WIDE=0 keeps the 64 x 64 blocks for comparisons
+bool wgrad3_wide() {
+    static const bool v = [] { const char* e = getenv("SF_WGRAD3_WIDE"); return !(e && e[0] == '0'); }();
     return v;
 }
 
@@ -992,15 +1076,21 @@ extern "C" int sf_set_wgrad_scheduling(int dynamic) {
     return SF_OK;
 }
 
+// wide blocks pay when the layer has a second 64-channel block of outputs
+static bool wgrad3_use_wide(int K) { return K > 64 && wgrad3_wide(); }
+
 extern "C" size_t sf_wgrad3x3_workspace_bytes(int N, int H, int W, int K, int Cin) {
     (void)N; (void)H; (void)W;
+    const size_t wide = sizeof(float) * (size_t)slices_for_wide(K, Cin, false) * ((K + 127) / 128 * 128) * 9 * ((Cin + 63) / 64 * 64);
+    const size_t narrow = sizeof(float) * (size_t)slices_for(K, Cin) * ((K + 63) / 64 * 64) * 9 * ((Cin + 63) / 64 * 64);
+    if (K > 64) return wide > narrow ? wide : narrow;
     return sizeof(float) * (size_t)slices_for(K, Cin) * ((K + 63) / 64 * 64) * 9 * ((Cin + 63) / 64 * 64);
 }
 
 extern "C" size_t sf_wgrad4x4s2_workspace_bytes(int N, int IH, int IW, int K, int Cin) {
     (void)N; (void)IH; (void)IW;
     if (!wgrad4_old())
-        return sizeof(float) * (size_t)slices_for_s2(K, Cin) * ((K + 127) / 128 * 128) * 16 * ((Cin + 63) / 64 * 64);
+        return sizeof(float) * (size_t)slices_for_wide(K, Cin, true) * ((K + 127) / 128 * 128) * 16 * ((Cin + 63) / 64 * 64);
     return sizeof(float) * (size_t)slices_for(K, Cin) * ((K + 63) / 64 * 64) * 16 * ((Cin + 63) / 64 * 64);
 }
 
@@ -1016,8 +1106,11 @@ static int wgrad_common_checks(const char* who, const void* x, const void* dout,
 extern "C" int sf_wgrad3x3(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, int N, int H, int W,
                            int Cx, int Kd, int K, int Cin, void* stream) {
     if (int rc = wgrad_common_checks("sf_wgrad3x3", x, dout, dw, ws, N, H, W, Cx, Kd, K, Cin)) return rc;
-    return run_wgrad3_dma(x, dout, dw, ws, ws_bytes, sf_wgrad3x3_workspace_bytes(N, H, W, K, Cin), N, H, W, Cx, Kd, K,
-                          Cin, (hipStream_t)stream);
+    const size_t need = sf_wgrad3x3_workspace_bytes(N, H, W, K, Cin);
+    if (wgrad3_use_wide(K))
+        return run_wgrad_wide<WideCfg<false, 160, 256, 2>>("sf_wgrad3x3", x, dout, dw, ws, ws_bytes, need, N, H, W, H, W, Cx, Kd,
+                                                            K, Cin, (hipStream_t)stream);
+    return run_wgrad3_dma(x, dout, dw, ws, ws_bytes, need, N, H, W, Cx, Kd, K, Cin, (hipStream_t)stream);
 }
 
 extern "C" int sf_wgrad4x4s2(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, int N, int IH,
@@ -1026,15 +1119,9 @@ extern "C" int sf_wgrad4x4s2(const void* x, const void* dout, float* dw, float* 
     SF_REQUIRE(IH >= 2 && IW >= 2, "sf_wgrad4x4s2: input smaller than the filter footprint");
     const int OH = (IH - 2) / 2 + 1, OW = (IW - 2) / 2 + 1;
     if (!wgrad4_old())
-    {
-        const size_t need = sf_wgrad4x4s2_workspace_bytes(N, IH, IW, K, Cin);
-        hipStream_t s = (hipStream_t)stream;
-        switch (wgrad4_ring()) {
-        case 3: return run_wgrad4s2_dma<S2W<80, 224, 3>>(x, dout, dw, ws, ws_bytes, need, N, IH, IW, OH, OW, Cx, Kd, K, Cin, s);
-        case 4: return run_wgrad4s2_dma<S2W<64, 192, 4>>(x, dout, dw, ws, ws_bytes, need, N, IH, IW, OH, OW, Cx, Kd, K, Cin, s);
-        default: return run_wgrad4s2_dma<S2W<128, 320, 2>>(x, dout, dw, ws, ws_bytes, need, N, IH, IW, OH, OW, Cx, Kd, K, Cin, s);
-        }
-    }
+        return run_wgrad_wide<WideCfg<true, 128, 320, 2>>("sf_wgrad4x4s2", x, dout, dw, ws, ws_bytes,
+                                                           sf_wgrad4x4s2_workspace_bytes(N, IH, IW, K, Cin), N, IH, IW, OH, OW, Cx,
+                                                           Kd, K, Cin, (hipStream_t)stream);
     return run_wgrad<16, 2>(x, dout, dw, ws, ws_bytes, sf_wgrad4x4s2_workspace_bytes(N, IH, IW, K, Cin), N, IH, IW, OH,
                             OW, Cx, Kd, K, Cin, (hipStream_t)stream, "sf_wgrad4x4s2");
 }

@@ -477,7 +477,9 @@ def test_wgrad3x3_matches_generic(sf):
     operands (both accumulate in f32): odd sizes, partial tiles, channel counts below one tile."""
     ops = sf.ops
     torch.manual_seed(0)
-    for (N, H, W, C, K) in [(2, 37, 53, 16, 24), (1, 100, 100, 64, 64), (3, 20, 200, 136, 72)]:
+    # (more than 64 output channels: blocks of 128 x 64 with all nine taps per wave)
+    for (N, H, W, C, K) in [(2, 37, 53, 16, 24), (1, 100, 100, 64, 64), (3, 20, 200, 136, 72), (2, 33, 41, 72, 200),
+                            (1, 5, 7, 64, 128)]:
         x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
         dz = torch.randn(N, H, W, K, device=DEV).to(torch.bfloat16)
         dw_a = torch.empty(K, C, 3, 3, device=DEV)
