@@ -11,6 +11,7 @@
 // chunk (latency hidden behind compute; a second resident workgroup covers the LDS store
 // burst).  D is kept as [kout][pixel] so a lane stores 4 consecutive channels per access.
 #include "sf_common.h"
+#include <type_traits>
 #include "../../include/sfhip.h"
 #include <atomic>
 
@@ -379,13 +380,21 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         const int c0 = it.chunk * CK;
         const bf16* wbase = p.wstaged ? p.w + ((size_t)(it.k0 / KT) * p.nchunks + it.chunk) * (D_WIMG / 2)
                                       : p.w + (size_t)it.k0 * 9 * p.C + c0;
+#ifdef SF_CONV3_DIAG_SAMETILE     // timing only: every patch copy fetches the same pixels (L2 hits)
+        const bf16* ibase = p.in + c0;
+#else
         const bf16* ibase = p.in + (size_t)it.n * p.H * p.W * p.C + c0;
+#endif
         const unsigned wbytes = !live ? 0u : p.wstaged ? (unsigned)D_WIMG : (unsigned)(((p.K - it.k0) * 9 * p.C - c0) * 2);
         const unsigned ibytes = live ? (unsigned)((p.H * p.W * p.C - c0) * 2) : 0u;
         StageSrc ss;
         ss.wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wbytes, 0x00020000);
         ss.irs = __builtin_amdgcn_make_buffer_rsrc((void*)ibase, 0, ibytes, 0x00020000);
+#ifdef SF_CONV3_DIAG_SAMETILE
+        ss.ym1 = -1; ss.xm1 = -1;
+#else
         ss.ym1 = it.y0 - 1; ss.xm1 = it.x0 - 1;
+#endif
         ss.ioff = ((ss.ym1 * p.W + ss.xm1) * p.C) * 2;
         return ss;
     };
@@ -431,7 +440,8 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         for (int j = 0; j < 4; ++j) {
             const int q = wave * 64 + c * 32 + (lane >> 3) + 8 * j;
             const int ly = q / p.TW;
-            st_lyx[c][j] = (RES || EPI == 1) ? (ly << 16) | (q - ly * p.TW) : 0;
+            // (a pixel beyond the tile gets a row no image has, so one comparison rejects it)
+            st_lyx[c][j] = (RES || EPI == 1) ? (q < TP ? (ly << 16) | (q - ly * p.TW) : 0x7fff0000) : 0;
         }
     // byte offset of the lane's B fragment in the patch image for tap t, reduction step 0
     // (step 1, 64-byte rows only, is the same offset ^ 32): tile-invariant, so computed once
@@ -462,8 +472,11 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // before the 2 MT MFMAs of position i (pinned order, counted lgkmcnt).
     // One copy piece of the next stage is issued per position (an LDS-DMA instruction holds the
     // issuing wave for ~100 cycles; spread out, the other wave's MFMAs cover it).
-    auto run_stage = [&](const char* __restrict__ cur, char* __restrict__ fill, const StageSrc& ss,
+    // `first` (a compile-time flag): the stage opens an item, its first MFMAs start from zero instead
+    // of the accumulators (which then need no clearing after the epilogue)
+    auto run_stage = [&](auto first, const char* __restrict__ cur, char* __restrict__ fill, const StageSrc& ss,
                          const char* __restrict__ wts) {
+        constexpr bool FIRST = decltype(first)::value;
         const char* wl0 = wts + aLane0;
         const char* wl1 = wts + aLane1;
         const char* pl = cur + P_OFF;
@@ -493,15 +506,30 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
             if (i + PF < NPOS) issue(i + PF);
+#ifdef SF_CONV3_DIAG_NOCOPY       // timing only: the stage buffers keep what the first copies brought
+            if (p.N < 0)
+#endif
 #pragma unroll
             for (int j = i * PPP; j < (i + 1) * PPP; ++j)
                 if (j < D_NWJ + D_NPJ) issue_piece(ss, fill, j);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef SF_CONV3_DIAG_NOMFMA    // timing only: copies, fragment reads and epilogue without the arithmetic
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % RING][a], fb[i % RING][c], acc[a][c], 0, 0, 0);
+                for (int c = 0; c < 2; ++c) {
+                    if (FIRST && i == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % RING][a], fb[i % RING][c], z, 0, 0, 0);
+                    } else {
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % RING][a], fb[i % RING][c], acc[a][c], 0, 0, 0);
+                    }
+                }
+#else
+            asm volatile("" ::"v"(fa[i % RING][0]), "v"(fb[i % RING][0]), "v"(fb[i % RING][1]));
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -523,16 +551,25 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int G = lane & 7;
+        // buffer stores into the item's image: a pixel outside the tile or the image gets an offset past
+        // the buffer's end and is dropped, so every wave issues exactly four stores per call (the
+        // stage loop counts them) and the addresses are 32-bit
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(reinterpret_cast<bf16*>(p.out) + (size_t)it.n * p.H * p.W * p.ldo), 0, (unsigned)(p.H * p.W * p.ldo * 2), 0x00020000);
+        // byte offset = item part (scalar) + ly * row bytes + lx * pixel bytes + the lane's piece; the
+        // host guarantees row bytes < 2^24, so the products are single 24-bit multiplies
+        const int sbase = ((it.y0 * p.W + it.x0) * p.ldo + it.k0 + half * 64) * 2;
+        const int hrem = p.H - it.y0, wrem = p.W - it.x0;
+        const unsigned row_b = (unsigned)(p.W * p.ldo * 2), px_b = (unsigned)(p.ldo * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pr = (lane >> 3) + 8 * j;                   // pixel row of the slice
             const u32x4 v = *reinterpret_cast<const u32x4*>(lines + wave * 4096 + pr * 128 + ((G ^ ((pr >> 1) & 7)) << 4));
-            const int q = wave * 64 + c * 32 + pr;
             const int ly = st_lyx[c][j] >> 16, lx = st_lyx[c][j] & 0xffff;   // q / TW, q % TW: tile-invariant
-            const int gy = it.y0 + ly, gx = it.x0 + lx;
-            if (q < TP && gy < p.H && gx < p.W)
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.out) +
-                                            (((long long)it.n * p.H + gy) * p.W + gx) * p.ldo + it.k0 + half * 64 + G * 8));
+            const bool ok = ly < hrem && lx < wrem;
+            const int voff = ok ? (int)(__umul24((unsigned)ly, row_b) + __umul24((unsigned)lx, px_b)) + sbase + G * 16
+                                : (int)0x80000000;
+            __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, 2);      // aux 2 = nt (streaming)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                          // the slice is rewritten for the next pieces
@@ -667,7 +704,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                         const auto s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
                         const int k = it.k0 + a * 32 + 8 * (2 * gp + h);
-                        if (LINES && lines) {
+                        if (LINES && (SP || lines)) {      // the fixed epilogues always stage whole lines
                             // row r of the wave's slice, 16-byte slot (channel group of the 64-channel half) XOR (r >> 1) & 7
                             const int G = (a & 1) * 4 + 2 * gp + h;
                             *reinterpret_cast<uint4*>(lines + wave * 4096 + r * 128 + ((G ^ ((r >> 1) & 7)) << 4)) =
@@ -697,7 +734,13 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
                 }
             if (RES && dot && wide_out) {
                 dsum += __shfl_xor(dsum, 32, 64);        // the other 32 channels of the pixel
-                if (h == 0 && pv[c]) p.dot_out[pixidx[c]] = dsum + dot_b0;
+                if (SP) {       // one store per wave and pixel tile, whatever the lanes' pixels (counted by the stage loop)
+                    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(p.dot_out + (size_t)it.n * p.H * p.W), 0, (unsigned)(p.H * p.W * 4), 0x00020000);
+                    const int gy = it.y0 + (lyx[c] >> 16), gx = it.x0 + (lyx[c] & 0xffff);
+                    const int voff = (h == 0 && pv[c]) ? (gy * p.W + gx) * 4 : (int)0x80000000;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dsum + dot_b0), drs, voff, 0, 0);
+                } else if (h == 0 && pv[c]) p.dot_out[pixidx[c]] = dsum + dot_b0;
             }
         }
     };
@@ -754,24 +797,47 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         }
     };
     advance(nxt);
+    // The barrier between two stages.  The copies of a stage are older than the output stores of the
+    // epilogue that follows them, and vector-memory operations retire in issue order: behind an
+    // epilogue the wave waits until only its NST stores are left, so the stores drain under the next
+    // stage instead of holding every wave at the barrier for a write round trip.  (The fixed-epilogue
+    // variants issue exactly NST stores per item and wave; the run-time epilogue drains everything.)
+    constexpr int NST = 4 * MT + (EPI == 2 ? 2 : 0);
+    bool after_epi = false;
+    auto stage_sync = [&]() {
+#ifndef SF_CONV3_DIAG_DRAIN
+        if (SP && after_epi) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
+        else
+#endif
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        after_epi = false;
+    };
     // one step of the pipeline; `cur_buf` holds the landed stage, `fill` takes the next copy
     auto step = [&](const char* __restrict__ cur_buf, char* __restrict__ fill) {
         const StageSrc ss = stage_src(nxt, nxt.q < nitems);
         if (EPI == 3 && cur.chunk == p.nchunks - 1) aux_prefetch(cur);
-        run_stage(cur_buf, fill, ss, RES ? smd + cur.chunk * D_WIMG : cur_buf);
+        if (SP && cur.chunk == 0) run_stage(std::true_type{}, cur_buf, fill, ss, RES ? smd + cur.chunk * D_WIMG : cur_buf);
+        else run_stage(std::false_type{}, cur_buf, fill, ss, RES ? smd + cur.chunk * D_WIMG : cur_buf);
         SF_STAMP(2);
         if (cur.chunk == p.nchunks - 1) {
             char* lines = nullptr;
             if (RES && line_stores) {
-                __syncthreads();          // every wave is done reading the patch the pieces are parked in
+                // every wave is done reading the patch the pieces are parked in (its LDS reads have
+                // returned); the copies of the next stage stay in flight
+                if (SP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else __syncthreads();
                 lines = const_cast<char*>(cur_buf);
             } else if (EPI == 1) {
                 lines = smd + 2 * D_BUF + sizeof(float) * D_BIAS_MAX;
             }
             SF_STAMP(4);
+#ifdef SF_CONV3_DIAG_NOEPI        // timing only: nothing is stored (the condition is never true, the MFMAs stay)
+            if (p.N < 0)
+#endif
             epilogue(cur, lines);
             SF_STAMP(5);
-            zero_acc();
+            if (!SP) zero_acc();
+            after_epi = true;
         }
         cur = nxt;
         advance(nxt);
@@ -783,7 +849,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         // the stage's copy has landed (own vmcnt, then the barrier) and every wave is done
         // reading the buffer the next copy goes to
         SF_STAMP(0);
-        __syncthreads();
+        stage_sync();
         SF_STAMP(1);
         park();
         step(buf0, buf1);
@@ -793,7 +859,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
 #endif
         if (cur.q >= nitems) break;
         SF_STAMP(0);
-        __syncthreads();
+        stage_sync();
         SF_STAMP(1);
         park();
         step(buf1, buf0);
@@ -863,6 +929,8 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
         epi = 1;
     if (RES && lines && p.bias && p.act == SF_ACT_RELU && !p.aux_mode && p.dot_out) epi = 2;
     if (RES && lines && !p.bias && p.act == SF_ACT_NONE && p.aux_mode == 1 && !p.dot_out) epi = 3;
+    // the fixed epilogues address the output with 32-bit byte offsets inside one image, built from 24-bit products
+    if (2LL * p.H * p.W * p.ldo >= 0x7fffffffLL || 2LL * p.W * p.ldo >= (1 << 24) || p.H >= 0x7fff) epi = 0;
 #ifdef SF_CONV3_GENERIC_EPILOGUE
     epi = 0;     // diagnostic build (A/B timing): every call on the run-time epilogue
 #endif
