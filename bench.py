@@ -158,6 +158,9 @@ def main():
                          "of the multi-rank path on a one-GPU box, not a measurement")
     ap.add_argument("--static-wgrad", action="store_true",
                     help="distributed / rehearsal runs: keep the weight-gradient kernel's fixed tile slices")
+    ap.add_argument("--shard-big", action="store_true",
+                    help="distributed runs: reduce-scatter the two big Linear gradients, Adam on each rank's slice, "
+                         "all-gather the bf16 shadow (system.dp_shard_big) instead of the all-reduce")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -189,6 +192,8 @@ def main():
     cfg = bench_config(a.batch)
     if a.static_wgrad:
         cfg["system"]["dp_dynamic_wgrad"] = False
+    if a.shard_big:
+        cfg["system"]["dp_shard_big"] = True
     torch.manual_seed(0)
     region = cfg["data"]["region"]
 
@@ -342,6 +347,7 @@ def main():
             out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
             out["comm_transport"] = "rccl" if dist.get_backend() == "nccl" else f"{dist.get_backend()} (staged through host memory)"
             out["comm_exposed_ms"] = round(comm_ms, 4)
+            out["big_gradients"] = "reduce-scatter + sliced Adam + all-gather of the bf16 shadow" if trainer.shard_big else "all-reduce"
         if with_loader is not None:
             out["with_loader"] = with_loader
         if rehearse:

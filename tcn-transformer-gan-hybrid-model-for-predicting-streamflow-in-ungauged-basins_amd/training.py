@@ -122,9 +122,13 @@ class FlatAdam:
             torch._foreach_copy_(dst, src)
         self._spans = spans
 
-    def step(self, grad_scale: float = 1.0, found_inf: Optional[torch.Tensor] = None):
+    def step(self, grad_scale: float = 1.0, found_inf: Optional[torch.Tensor] = None,
+             shards: Optional[Dict[int, Tuple[int, int, torch.Tensor]]] = None):
         """One Adam update from the gathered small gradients and the big parameters' own gradient
-        tensors; skipped as a whole (step count included) when found_inf[0] != 0 on the device."""
+        tensors; skipped as a whole (step count included) when found_inf[0] != 0 on the device.
+        shards: {index into self.big: (lo, hi, gradient of elements lo..hi)} -- only that range of
+        the parameter, its moments and its bf16 shadow is updated (a data-parallel rank that owns
+        one slice of the parameter; the caller exchanges the slices afterwards)."""
         b1, b2 = self.betas
         ops.adam_begin(self.state, found_inf)
         for (a, e, off) in self._spans:     # alignment gaps inside a span hold zero gradients and zero parameters
@@ -136,8 +140,14 @@ class FlatAdam:
             if p.grad is None:
                 continue
             shadow = ops.weight_shadow(p) if self.shadow_big else None
-            ops.adam_guarded(fl, p.grad.contiguous().view(-1), m, v, self.lr, b1, b2, self.eps, self.state, found_inf,
-                             grad_scale, shadow=shadow, step_offset=self._seen[ns + i] - self._calls)
+            if shards is not None and i in shards:
+                lo, hi, g = shards[i]
+                ops.adam_guarded(fl[lo:hi], g, m[lo:hi], v[lo:hi], self.lr, b1, b2, self.eps, self.state, found_inf,
+                                 grad_scale, shadow=None if shadow is None else shadow.view(-1)[lo:hi],
+                                 step_offset=self._seen[ns + i] - self._calls)
+            else:
+                ops.adam_guarded(fl, p.grad.contiguous().view(-1), m, v, self.lr, b1, b2, self.eps, self.state, found_inf,
+                                 grad_scale, shadow=shadow, step_offset=self._seen[ns + i] - self._calls)
             if shadow is not None:
                 shadowed.append(p)
         self._calls += 1
@@ -248,6 +258,24 @@ class Trainer:
             ops.set_wgrad_scheduling(bool(scfg.get("dp_dynamic_wgrad", True)))
             self._broadcast_initial_state()
             self._install_early_reduce()
+        # system.dp_shard_big: every rank owns 1 / world of each big parameter.  The gradient is
+        # reduce-scattered instead of all-reduced, Adam updates the rank's slice (parameter, moments,
+        # bf16 shadow) and the shadow slices are all-gathered: 1.5 x the parameter's bytes on the links
+        # instead of 2 x, and 1 / world of the optimiser pass.  The f32 parameter and the moments
+        # outside the own slice go stale until consolidate() (a collective) gathers them, which
+        # state_dict / save_* do.  Needs mixed precision (the forward pass reads the shadow) and sizes
+        # that divide by the world size; off by default.
+        self.shard_big = False
+        if self.distributed and bool(scfg.get("dp_shard_big", False)):
+            ok = self.use_amp and self.opt_g.shadow_big and self.opt_g.big and all(p.numel() % self.world == 0 for p in self.opt_g.big)
+            if not ok:
+                self.logger.warning("dp_shard_big ignored: needs mixed precision and big parameters divisible by the world size")
+            else:
+                self.shard_big = True
+                self._rank = dist.get_rank()
+                self._shard_grads = [torch.empty(p.numel() // self.world, device=self.device, dtype=torch.float32)
+                                     for p in self.opt_g.big]
+                self._stale_master = False
 
     # ---- data parallel ------------------------------------------------------------------
     def _broadcast_initial_state(self):
@@ -303,12 +331,73 @@ class Trainer:
         complete long before the encoder's backward finishes, so each is all-reduced in place
         from a post-accumulate hook and overlaps with the remaining backward kernels.  Hooks run
         in the order of the backward graph, which is the same on every rank."""
-        for p in self.opt_g.big:
-            def hook(param):
+        for i, p in enumerate(self.opt_g.big):
+            def hook(param, i=i):
                 if self._reduce_now:
-                    self._all_reduce(param.grad)
+                    if self.shard_big:
+                        self._reduce_scatter(param.grad, self._shard_grads[i])
+                    else:
+                        self._all_reduce(param.grad)
 
             p.register_post_accumulate_grad_hook(hook)
+
+    def _shard_range(self, p: torch.Tensor) -> Tuple[int, int]:
+        n = p.numel() // self.world
+        return self._rank * n, (self._rank + 1) * n
+
+    def _reduce_scatter(self, g: torch.Tensor, out: torch.Tensor):
+        """out = this rank's slice of the sum of `g` over the ranks (ordering as in _all_reduce)."""
+        flat = g.contiguous().view(-1)
+        if self._device_collectives:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ready)
+                work = dist.reduce_scatter_tensor(out, flat, async_op=True)
+            self._pending.append(work)
+        else:
+            t0 = time.perf_counter() if self.comm_events is not None else 0.0
+            host = flat.detach().to("cpu")
+            dist.all_reduce(host)           # host transports: reduce everything, keep the slice
+            n = out.numel()
+            out.copy_(host[self._rank * n:(self._rank + 1) * n], non_blocking=False)
+            if self.comm_events is not None:
+                self.comm_host_s += time.perf_counter() - t0
+
+    def _all_gather_slices(self, full: torch.Tensor):
+        """Every rank's slice of the flat tensor `full` (its own slice is current) to every rank, in place."""
+        n = full.numel() // self.world
+        mine = full[self._rank * n:(self._rank + 1) * n]
+        if self._device_collectives:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ready)
+                work = dist.all_gather_into_tensor(full, mine, async_op=True)
+            self._pending.append(work)
+        else:
+            t0 = time.perf_counter() if self.comm_events is not None else 0.0
+            host = mine.detach().to("cpu")
+            host = host.view(torch.uint8) if host.dtype == torch.bfloat16 else host     # (gloo has no bf16: as bytes)
+            parts = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(parts, host)
+            got = torch.cat(parts)
+            full.copy_(got.view(torch.bfloat16) if full.dtype == torch.bfloat16 else got, non_blocking=False)
+            if self.comm_events is not None:
+                self.comm_host_s += time.perf_counter() - t0
+
+    def consolidate(self):
+        """Sharded big parameters: gathers the f32 parameter and both Adam moments of every rank's
+        slice, so that each rank holds the whole state again.  A collective: every rank must call it
+        (state_dict and the save_* methods do); a no-op otherwise."""
+        if not self.shard_big or not self._stale_master:
+            return
+        self._wait_reduces()
+        for (fl, m, v) in self.opt_g._big_views:
+            for t in (fl, m, v):
+                self._all_gather_slices(t)
+        self._wait_reduces()
+        self._stale_master = False
 
     def _wait_reduces(self):
         """The compute stream waits for the collectives issued so far (the host does not).  With
@@ -367,6 +456,8 @@ class Trainer:
         gradients hold Inf/NaN is skipped on the device, as GradScaler.step does (src/train.py:255-260)."""
         bi = self.batch_idx
         self.model.train()
+        if self.shard_big:
+            self._wait_reduces()        # the shadow slices gathered after the previous step
         stepping = (bi + 1) % self.accum == 0
         d_batch = self.use_gan and bi % self.d_update_interval == 0
         self._reduce_now = self.distributed and stepping
@@ -448,12 +539,28 @@ class Trainer:
         GradScaler.step decides per optimiser (src/train.py:255-260); the check runs after the
         exchange, so every rank takes the same decision."""
         found = None
+        sharded = self.shard_big and opt is self.opt_g
         if self.use_amp:
             found = self.found_inf[which:which + 1]
             found.zero_()
-            for g in opt.grads():
+            for g in ([opt.gsmall] + self._shard_grads if sharded else opt.grads()):
                 ops.nan_inf_flag(g, found)
-        opt.step(scale, found)
+            if sharded:     # a rank sees its own slices only: the decision is the OR over the ranks
+                if self._device_collectives:
+                    dist.all_reduce(found, op=dist.ReduceOp.MAX)
+                else:
+                    host = found.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.MAX)
+                    found.copy_(host)
+        if sharded:
+            shards = {i: self._shard_range(p) + (self._shard_grads[i],) for i, p in enumerate(opt.big) if p.grad is not None}
+            opt.step(scale, found, shards=shards)
+            for i, p in enumerate(opt.big):
+                if i in shards:
+                    self._all_gather_slices(ops.weight_shadow(p).view(-1))
+            self._stale_master = True
+        else:
+            opt.step(scale, found)
         opt.zero_grad()
 
     # ---- epochs ---------------------------------------------------------------------------
@@ -589,6 +696,7 @@ class Trainer:
         return any(self.nan_report()["flags"])
 
     def state_dict(self):
+        self.consolidate()
         return self.model.state_dict()
 
     # ---- checkpoints ----------------------------------------------------------------------
@@ -596,6 +704,7 @@ class Trainer:
         """The reference's checkpoint (src/train.py:472-490): the generator's bare state_dict,
         f32, reference keys.  Tensors are cloned to the host first: parameters are views into one
         flat buffer, and torch.save of a view would write the whole buffer once per parameter."""
+        self.consolidate()
         torch.save(_host_state(self.model), path)
 
     def save_checkpoint(self, path: str):
@@ -603,6 +712,7 @@ class Trainer:
         both Adam states (step, moments per parameter name), the batch counter that drives the
         discriminator / accumulation schedule and the CPU generator state dropout seeds come from.
         Plain tensors, ints and strings only (loads with weights_only=True)."""
+        self.consolidate()
         ck = {"format": RESUME_FORMAT, "model": _host_state(self.model), "opt_g": self.opt_g.state_by_name(self.model),
               "batch_idx": int(self.batch_idx), "epoch": int(self.epoch), "cpu_rng_state": torch.get_rng_state()}
         if self.use_gan:
