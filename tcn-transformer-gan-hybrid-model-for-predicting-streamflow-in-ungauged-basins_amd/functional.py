@@ -185,9 +185,35 @@ class EncoderFn(torch.autograd.Function):
         return (dx, None, None, None, None, *grads)
 
 
+def _tap_chunks(ntaps: int):
+    """The gathered GEMM takes 16 filter taps per launch; larger filters run as a sum over tap groups."""
+    return [list(range(i, min(i + 16, ntaps))) for i in range(0, ntaps, 16)]
+
+
+def _conv_by_tap_groups(x, wt, out_shape, cdtype, transpose, rows_pad, cols_pad, geom_of):
+    """conv of NHWC `x` with OIHW weight `wt` as the sum over groups of at most 16 taps (conv is
+    linear in the filter): one group writes the output directly, several are summed in f32 and
+    rounded once.  geom_of(group) is the gathered-GEMM geometry of the group's taps."""
+    nt = wt.shape[2] * wt.shape[3]
+    groups = _tap_chunks(nt)
+    if len(groups) == 1:
+        out = torch.empty(out_shape, device=x.device, dtype=cdtype)
+        ops.conv_fprop(x, ops.pack_conv_weight(wt.detach().contiguous(), cdtype, groups[0], transpose, rows_pad, cols_pad), out,
+                       geom_of(groups[0]), rows_pad)
+        return out
+    acc = None
+    for grp in groups:
+        part = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+        ops.conv_fprop(x, ops.pack_conv_weight(wt.detach().contiguous(), cdtype, grp, transpose, rows_pad, cols_pad), part,
+                       geom_of(grp), rows_pad)
+        acc = part if acc is None else acc.add_(part)
+    return acc if cdtype == torch.float32 else ops.cast(acc, cdtype)
+
+
 class EncoderGeneralFn(torch.autograd.Function):
     """CNNEncoder.forward for the constructor options the model class itself never uses
-    (src/model/cnn_encoder.py:16-18,44-61): kernel_size k with k * k <= 16 taps, any padding, and
+    (src/model/cnn_encoder.py:16-18,44-61): kernel_size up to 8 (more than 16 taps: summed over
+    tap groups), any padding the tap offsets allow, and
     use_batchnorm=False (convs with bias, no normalisation).  Every conv runs on the gathered GEMM
     (forward, data gradient, weight gradient); a layer without BatchNorm goes through the
     BatchNorm passes with scale 1, shift = bias and frozen statistics, whose shift gradient is the
@@ -209,9 +235,9 @@ class EncoderGeneralFn(torch.autograd.Function):
             oh, ow = h + 2 * pad - ksize + 1, w + 2 * pad - ksize + 1
             if oh < 1 or ow < 1:
                 raise ValueError("CNNEncoder: the feature map vanished (kernel_size / padding against the image size)")
-            wp = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, list(range(ksize * ksize)), False, Kpad, C)
-            z = torch.empty((N, oh, ow, Kpad), device=x.device, dtype=cdtype)
-            ops.conv_fprop(a, wp, z, ops.conv_geom(N, h, w, C, oh, ow, 1, 1, oh, ow, taps), Kpad)
+            z = _conv_by_tap_groups(a, wt, (N, oh, ow, Kpad), cdtype, False, Kpad, C,
+                                    lambda g, h=h, w=w, C=C, oh=oh, ow=ow: ops.conv_geom(N, h, w, C, oh, ow, 1, 1, oh, ow,
+                                                                                         [taps[t] for t in g]))
             M = N * oh * ow
             if np_ == 5:
                 ws = None
@@ -241,7 +267,6 @@ class EncoderGeneralFn(torch.autograd.Function):
         ksize, pad, Cin = ctx.geom
         taps = [(r - pad, s - pad) for r in range(ksize) for s in range(ksize)]
         taps_T = [(pad - r, pad - s) for r in range(ksize) for s in range(ksize)]
-        rs = list(range(ksize * ksize))
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         L = len(layers)
         K_last = params[sum(layers[:-1])].shape[0]
@@ -259,17 +284,18 @@ class EncoderGeneralFn(torch.autograd.Function):
             gamma = ps[1].detach() if bn else torch.ones(K, device=z.device)
             dz, dgamma, dbeta = ops.bn_backward(1 if l == L - 1 else 0, z, dy, st, gamma, K, ctx.training and bn, th, tw)
             dw = torch.zeros_like(wt)
-            ops.conv_wgrad(a, dz, dw, ops.conv_geom(N, h, w, C, oh, ow, 1, 1, oh, ow, taps, tap_rs=rs,
-                                                    cin_real=wt.shape[1], RS=ksize * ksize), Kpad)
+            for grp in _tap_chunks(ksize * ksize):      # each group adds its own taps of dw
+                ops.conv_wgrad(a, dz, dw, ops.conv_geom(N, h, w, C, oh, ow, 1, 1, oh, ow, [taps[t] for t in grp], tap_rs=grp,
+                                                        cin_real=wt.shape[1], RS=ksize * ksize), Kpad)
             grads[pi] = dw
             if bn:
                 grads[pi + 1], grads[pi + 2] = dgamma, dbeta
             else:
                 grads[pi + 1] = dbeta
             if l > 0 or ctx.needs_input_grad[0]:
-                wT = ops.pack_conv_weight(wt.detach().contiguous(), cdtype, rs, True, C, Kpad)
-                da = torch.empty((N, h, w, C), device=dz.device, dtype=cdtype)
-                ops.conv_fprop(dz, wT, da, ops.conv_geom(N, oh, ow, Kpad, h, w, 1, 1, h, w, taps_T), C)
+                da = _conv_by_tap_groups(dz, wt, (N, h, w, C), cdtype, True, C, Kpad,
+                                         lambda g, h=h, w=w, oh=oh, ow=ow, Kpad=Kpad: ops.conv_geom(
+                                             N, oh, ow, Kpad, h, w, 1, 1, h, w, [taps_T[t] for t in g]))
                 if l > 0:
                     dy = da
                 else:

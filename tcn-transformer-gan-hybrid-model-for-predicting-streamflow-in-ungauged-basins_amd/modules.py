@@ -30,8 +30,9 @@ class CNNEncoder(nn.Module):
     def __init__(self, input_channels: int, hidden_dim: int, num_layers: int = 2, kernel_size: int = 3,
                  padding: int = 1, use_batchnorm: bool = True):
         super().__init__()
-        if kernel_size < 1 or kernel_size * kernel_size > 16 or padding < 0:
-            raise NotImplementedError("the HIP encoder gathers at most 16 filter taps: kernel_size 1 to 4")
+        if kernel_size < 1 or kernel_size > 8 or padding < 0 or padding > 7 or kernel_size - padding > 8:
+            raise NotImplementedError("the HIP encoder's gathered GEMM reaches tap offsets -8 .. 7 (forward and transposed): "
+                                      "kernel_size 1 to 8, padding 0 to 7, kernel_size - padding at most 8")
         self.input_channels = input_channels
         self.hidden_dim = hidden_dim
         self.num_layers = num_layers
@@ -158,26 +159,30 @@ class TransformerModule(nn.Module):
 
 
 class LSTMModule(nn.Module):
-    """Mirror of src/model/lstm_module.py:7-81 (unidirectional path; the reference model never
-    enables bidirectional, src/model/__init__.py:82-87)."""
+    """Mirror of src/model/lstm_module.py:7-81.  The reference model never enables bidirectional
+    (src/model/__init__.py:82-87); the option is built for one layer, where the backward
+    direction is the same recurrence over the reversed sequence with its own weights and the
+    result is [h_forward, h_backward] (src/model/lstm_module.py:69-73).  Deeper bidirectional
+    stacks feed both directions' whole sequences to the next layer, which the kernel (it keeps
+    only the last hidden state) does not provide."""
 
     def __init__(self, input_dim: int, hidden_dim: int, num_layers: int = 1, dropout: float = 0.2,
                  bidirectional: bool = False):
         super().__init__()
-        if bidirectional:
-            raise NotImplementedError("bidirectional LSTM is not on the reference's hot path and is not built")
-        self.input_dim, self.hidden_dim, self.num_layers, self.bidirectional = input_dim, hidden_dim, num_layers, False
+        if bidirectional and num_layers != 1:
+            raise NotImplementedError("bidirectional LSTM is built for num_layers = 1 only (the reference model never enables it)")
+        self.input_dim, self.hidden_dim, self.num_layers, self.bidirectional = input_dim, hidden_dim, num_layers, bool(bidirectional)
         self.input_proj = nn.Linear(input_dim, hidden_dim) if input_dim != hidden_dim else None
         self.lstm = nn.LSTM(input_size=hidden_dim, hidden_size=hidden_dim, num_layers=num_layers,
-                            dropout=dropout if num_layers > 1 else 0, bidirectional=False, batch_first=True)
+                            dropout=dropout if num_layers > 1 else 0, bidirectional=self.bidirectional, batch_first=True)
         self.dropout = dropout if num_layers > 1 else 0.0
-        self.output_dim = hidden_dim
+        self.output_dim = hidden_dim * 2 if self.bidirectional else hidden_dim
 
-    def _weights(self):
+    def _weights(self, suffix: str = ""):
         ws = []
         for l in range(self.num_layers):
-            ws += [getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}"),
-                   getattr(self.lstm, f"bias_ih_l{l}"), getattr(self.lstm, f"bias_hh_l{l}")]
+            ws += [getattr(self.lstm, f"weight_ih_l{l}{suffix}"), getattr(self.lstm, f"weight_hh_l{l}{suffix}"),
+                   getattr(self.lstm, f"bias_ih_l{l}{suffix}"), getattr(self.lstm, f"bias_hh_l{l}{suffix}")]
         return ws
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -187,7 +192,11 @@ class LSTMModule(nn.Module):
             x = SF.linear(x.reshape(B * T, -1), self.input_proj, SF.compute_dtype()).view(B, T, -1)
         p = self.dropout if self.training else 0.0
         seed = SF.new_seed() if p > 0 else 0
-        return SF.LstmFn.apply(x, self.num_layers, p, seed, *self._weights())
+        h = SF.LstmFn.apply(x, self.num_layers, p, seed, *self._weights())
+        if not self.bidirectional:
+            return h
+        hb = SF.LstmFn.apply(x.flip(1), 1, 0.0, 0, *self._weights("_reverse"))
+        return torch.cat([h, hb], dim=1)
 
     def get_output_dim(self) -> int:
         return self.output_dim

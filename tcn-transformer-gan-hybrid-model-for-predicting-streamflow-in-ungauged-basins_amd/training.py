@@ -615,12 +615,18 @@ class Trainer:
         output_dir.mkdir(parents=True, exist_ok=True)
         self._attach_file_log(output_dir)
         rank = dist.get_rank() if self.distributed else 0
+        # map-style datasets: worker processes, page-locked batches (src/train.py:374-376, default 4 workers)
+        nw = int(self.config.get("train", {}).get("num_workers", 4))
+        pin = self.device.type == "cuda"
+        self._train_loaders, self._val_loaders = {}, {}
         for epoch in range(num_epochs):
             self.epoch = epoch
-            train_metrics = self.train_epoch(_epoch_loader(train_dataset, batch_size, True, epoch, rank, self.world))
+            train_metrics = self.train_epoch(_epoch_loader(train_dataset, batch_size, True, epoch, rank, self.world, nw, pin,
+                                                           self._train_loaders))
             self.logger.info(f"Epoch {epoch} - Train Loss: {train_metrics['loss']:.6f}")
+            self.consolidate()      # sliced big parameters: every rank, before rank 0 alone decides what to save
             if val_dataset is not None:
-                val_metrics = self.validate(_epoch_loader(val_dataset, batch_size, False, epoch, 0, 1))
+                val_metrics = self.validate(_epoch_loader(val_dataset, batch_size, False, epoch, 0, 1, nw, pin, self._val_loaders))
                 self.logger.info(f"Epoch {epoch} - Val Loss: {val_metrics['loss']:.6f}, "
                                  f"RMSE: {val_metrics['RMSE']:.4f}, NSE: {val_metrics['NSE']:.4f}")
                 if val_metrics["loss"] < self.best_loss:
@@ -767,22 +773,35 @@ class _ListLoader:
         return iter(self._make())
 
 
-def _epoch_loader(dataset, batch_size: int, shuffle: bool, epoch: int, rank: int, world: int):
+def _epoch_loader(dataset, batch_size: int, shuffle: bool, epoch: int, rank: int, world: int, num_workers: int = 0,
+                  pin_memory: bool = False, cache: Optional[Dict] = None):
     """Batches of one epoch.  A dataset with a loader() method (ResidentStreamflowDataset) serves
     them from HBM, sharded over the ranks; any other map-style dataset goes through
-    torch.utils.data.DataLoader with the reference's collate function (src/train.py:392-401)."""
+    torch.utils.data.DataLoader as in src/train.py:374-401: the reference's collate function,
+    `num_workers` worker processes that stay alive between epochs (the loader is kept in `cache`),
+    two batches prefetched per worker, page-locked batches when the trainer sits on a GPU."""
     if hasattr(dataset, "loader"):
         n = len(dataset) // world
         nb = (n + batch_size - 1) // batch_size
         return _ListLoader(lambda: dataset.loader(batch_size, shuffle=shuffle, seed=0, epoch=epoch, rank=rank, world=world), nb)
     from torch.utils.data import DataLoader
-    sampler = None
-    if world > 1:
-        from torch.utils.data.distributed import DistributedSampler
-        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=0)
+    key = (id(dataset), batch_size, shuffle, rank, world, num_workers, pin_memory)
+    if cache is not None and key in cache:
+        loader, sampler = cache[key]
+    else:
+        sampler = None
+        if world > 1:
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=0)
+        loader = DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                            num_workers=num_workers, pin_memory=pin_memory, collate_fn=_collate,
+                            persistent_workers=num_workers > 0, prefetch_factor=2 if num_workers > 0 else None)
+        if cache is not None:
+            cache.clear()           # one dataset pair at a time: workers of loaders no longer used are released
+            cache[key] = (loader, sampler)
+    if sampler is not None:
         sampler.set_epoch(epoch)
-    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler, num_workers=0,
-                      collate_fn=_collate)
+    return loader
 
 
 def _host_state(module: nn.Module) -> Dict[str, torch.Tensor]:

@@ -2,6 +2,7 @@
 against the golden vectors produced by the reference.  f32 mode: <= 1e-5 relative to the
 tensor's max (north-star tolerance) for forward values, looser stated bounds for gradients that
 pass through ReLU / max-pool decisions; bf16 mode: stated tolerances in each test."""
+import copy
 import numpy as np
 import pytest
 import torch
@@ -880,6 +881,62 @@ def test_encoder_constructor_options_f32(sf, tag, k, pad, bn, size):
         close(enc(x0), g[f"enc_{tag}_y"], 3e-2)
     finally:
         sf.set_compute_dtype(None)
+
+
+@pytest.mark.parametrize("k,pad,bn", [(5, 2, True), (7, 3, True), (5, 0, False), (8, 4, True)])
+def test_encoder_large_filters_f32(sf, k, pad, bn):
+    """CNNEncoder with more than 16 filter taps (src/model/cnn_encoder.py:16-18,44-61): the convs run as
+    sums over groups of 16 taps.  No fixture of the reference covers these sizes (parity unpinned);
+    the check is the same layer stack (the module's own nn layers, which mirror the reference's
+    constructor) run by torch on the CPU in f32: forward 1e-5 of the maximum, gradients 1e-4."""
+    torch.manual_seed(31)
+    enc = sf.CNNEncoder(3, 8, 2, kernel_size=k, padding=pad, use_batchnorm=bn).to(DEV)
+    ref = copy.deepcopy(enc).cpu()
+    x0 = torch.randn(2, 3, 80, 72)
+    gy = torch.randn(2, 16, 32, 32)
+    for mode in ("eval", "train"):
+        getattr(enc, mode)()
+        getattr(ref, mode)()
+        x = x0.clone().to(DEV).requires_grad_(True)
+        xr = x0.clone().requires_grad_(True)
+        y = enc(x)
+        yr = ref.adaptive_pool(ref.encoder(xr))
+        close(y, yr.detach().numpy(), 1e-5)
+        (y * gy.to(DEV)).sum().backward()
+        (yr * gy).sum().backward()
+        close_robust(x.grad, xr.grad.numpy(), 1e-4)
+        for (n, p), (_, pr) in zip(enc.named_parameters(), ref.named_parameters()):
+            close(p.grad, pr.grad.numpy(), 1e-4)
+            p.grad = None
+            pr.grad = None
+    for (key, v), (_, vr) in zip(enc.state_dict().items(), ref.state_dict().items()):
+        if "running" in key:
+            close(v, vr.numpy(), 1e-5)
+
+
+def test_bidirectional_lstm_one_layer_f32(sf):
+    """LSTMModule(bidirectional=True), one layer (src/model/lstm_module.py:30-37,69-73): the last hidden
+    states of both directions, concatenated.  The reference model never enables the option and its
+    tests hold no fixture for it (parity unpinned); checked against torch's nn.LSTM on the CPU with
+    the same weights: output 1e-5, gradients 1e-4."""
+    torch.manual_seed(37)
+    mod = sf.LSTMModule(48, 32, num_layers=1, dropout=0.0, bidirectional=True).to(DEV)
+    ref = copy.deepcopy(mod).cpu()
+    assert mod.get_output_dim() == 64
+    x0 = torch.randn(5, 7, 48)
+    x, xr = x0.clone().to(DEV).requires_grad_(True), x0.clone().requires_grad_(True)
+    y = mod(x)
+    _, (hn, _) = ref.lstm(ref.input_proj(xr))
+    yr = hn.view(1, 2, 5, 32)[-1].transpose(0, 1).contiguous().view(5, -1)
+    close(y, yr.detach().numpy(), 1e-5)
+    gy = torch.randn(5, 64)
+    (y * gy.to(DEV)).sum().backward()
+    (yr * gy).sum().backward()
+    close(x.grad, xr.grad.numpy(), 1e-4)
+    for (n, p), (_, pr) in zip(mod.named_parameters(), ref.named_parameters()):
+        close(p.grad, pr.grad.numpy(), 1e-4)
+    with pytest.raises(NotImplementedError):
+        sf.LSTMModule(48, 32, num_layers=2, bidirectional=True)
 
 
 def test_discriminator_three_input_channels_f32(sf):

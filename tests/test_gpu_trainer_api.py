@@ -92,6 +92,57 @@ def test_train_writes_the_reference_checkpoint_files(sf, training, tmp_path):
     assert tr.epoch == 9 and np.isfinite(tr.best_loss)
 
 
+class _HostWindows(torch.utils.data.Dataset):
+    """A map-style dataset of host tensors, the shape of the reference's StreamflowDataset samples
+    (src/dataset.py:300-330): served by DataLoader worker processes, not from HBM."""
+
+    def __init__(self, batches):
+        self.samples = []
+        for b in batches:
+            for i in range(b["images"].shape[0]):
+                self.samples.append({"images": b["images"][i].cpu(), "output_image": b["output_image"][i].cpu(),
+                                     "stations": b["stations"][i], "station_positions": b["station_positions"][i]})
+        self.pids = torch.zeros(len(self.samples), dtype=torch.int64).share_memory_()
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        self.pids[i] = os.getpid()
+        return self.samples[i]
+
+
+def test_train_feeds_map_style_datasets_through_worker_processes(sf, training, tmp_path):
+    """A dataset without a loader() method goes through torch's DataLoader as in src/train.py:374-401:
+    train.num_workers worker processes (kept between epochs), page-locked batches.  Two epochs over
+    12 host-side samples: every sample was produced by a process other than the trainer's, by the
+    same workers in both epochs, and the run equals the same batches fed in process (num_workers 0)
+    when nothing is shuffled."""
+    cfg = train_cfg("LSTM", False, 1)
+    cfg["data"]["output_dir"] = str(tmp_path / "out")
+    cfg["train"]["batch_size"] = 4
+    cfg["train"]["num_workers"] = 2
+    ds = _HostWindows(make_batches(3, 4, 3, 64))
+    loaders = importlib.import_module(sf.__name__ + ".training")
+    cache = {}
+    ld = loaders._epoch_loader(ds, 4, False, 0, 0, 1, 2, True, cache)
+    first = [b for b in ld]
+    assert len(first) == 3 and first[0]["images"].is_pinned() and tuple(first[0]["images"].shape[:1]) == (4,)
+    workers = set(ds.pids.tolist())
+    assert os.getpid() not in workers and 1 <= len(workers) <= 2
+    ds.pids.zero_()
+    assert loaders._epoch_loader(ds, 4, False, 1, 0, 1, 2, True, cache) is ld      # the same loader, its workers alive
+    second = [b for b in ld]
+    assert set(ds.pids.tolist()) == workers
+    assert all(torch.equal(a["images"], b["images"]) for a, b in zip(first, second))
+    del ld, cache
+    torch.manual_seed(3)
+    tr = training.Trainer(cfg, device=DEV)
+    load_gold(tr.model, "trn_g_lstm")
+    tr.train(ds, num_epochs=2)
+    assert tr.epoch == 1 and not tr.saw_nan_or_inf()
+
+
 def test_nan_checks_warn_and_the_step_is_skipped(sf, training, caplog):
     """An Inf in the input images: the three warnings of src/train.py:193-199,221-222 appear, and
     with mixed precision the optimiser step is skipped as GradScaler.step skips it
