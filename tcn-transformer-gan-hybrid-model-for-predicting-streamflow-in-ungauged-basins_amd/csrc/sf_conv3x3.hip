@@ -44,12 +44,24 @@ StreamSlots g_slots;     // which queue slot the launches of a stream use
 // diagnostic build only (tools/conv_stamps.py): shader-clock stamps of wave 0 of every workgroup
 // around the barrier, the stage and the epilogue of its first STAMP_STEPS pipeline steps
 constexpr int STAMP_STEPS = 48;
+#ifdef SF_CONV3_STAMPS_ALLWAVES     // lane 0 of every wave: [workgroup][step][slot][wave]
+__device__ unsigned long long g_stamps[256 * STAMP_STEPS * 8 * 8];
+#define SF_STAMP(slot)                                                                              \
+    do {                                                                                            \
+        if ((tid & 63) == 0 && stamp_step < STAMP_STEPS)                                            \
+            g_stamps[((blockIdx.x * STAMP_STEPS + stamp_step) * 8 + (slot)) * 8 + (tid >> 6)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#ifdef SF_CONV3_STAMPS_POS          // + the end of every tap position of a stage: [workgroup][step][wave][position]
+__device__ unsigned long long g_pos_stamps[256 * STAMP_STEPS * 8 * 20];
+#endif
+#else
 __device__ unsigned long long g_stamps[256 * STAMP_STEPS * 8];
 #define SF_STAMP(slot)                                                                              \
     do {                                                                                            \
         if (tid == 0 && stamp_step < STAMP_STEPS)                                                   \
             g_stamps[(blockIdx.x * STAMP_STEPS + stamp_step) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#endif
 #else
 #define SF_STAMP(slot) do { } while (0)
 #endif
@@ -468,6 +480,9 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     };
     zero_acc();
 
+#ifdef SF_CONV3_STAMPS
+    int stamp_step = 0;
+#endif
     // One stage: 9 taps x KS reduction steps, the MT + 2 fragment reads of position i + 1 issued
     // before the 2 MT MFMAs of position i (pinned order, counted lgkmcnt).
     // One copy piece of the next stage is issued per position (an LDS-DMA instruction holds the
@@ -501,6 +516,9 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
 #endif
         constexpr int PPP = SF_CONV3_PPP;
         static_assert(D_NWJ + D_NPJ <= NPOS * PPP, "copy pieces per position");
+#if defined(SF_CONV3_DIAG_NOMFMA) || defined(SF_CONV3_BLOCKED)
+        // (the order of the first builds, kept for the timing-only build without MFMAs and for comparisons: all reads and
+        // copy pieces of a position, then its MFMAs)
 #pragma unroll
         for (int i = 0; i < PF; ++i) issue(i);
 #pragma unroll
@@ -532,6 +550,60 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
+#else
+        // Every fragment read of position i + PF and every copy piece of the position sits BEHIND one
+        // of position i's MFMAs (pinned): an in-order wave issues them while that MFMA occupies the
+        // matrix pipe.  Read order = order of first use.  (Worth 1 % on the resident shape, nothing on
+        // the wide one; neither were a two-set register ring that keeps reads twelve MFMAs ahead, nop
+        // padding between the MFMAs, a static priority for waves 4-7 or a start-up skew between the
+        // two waves of a SIMD.  What the wide shape loses at its stage barriers -- 20 % by the
+        // timing-only build without them -- is the older wave of each SIMD winning the matrix pipe
+        // and then idling at the barrier while the younger one runs its stage alone.)
+        constexpr int NM = 2 * MT, NR = MT + 2;
+        auto read_one = [&](int i, int m) {
+            const int t = i / KS, ks = i % KS, sl = i % RING;
+            // fa0, fb0, fb1, fa1, fa2, ...
+            if (m == 0 || m >= 3) {
+                const int a = m == 0 ? 0 : m - 2;
+                fa[sl][a] = *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (t * KT + a * 32) * ROWB);
+            } else {
+                fb[sl][m - 1] = *reinterpret_cast<const bf16x8*>(pl + (pa[m - 1][t] ^ (ks << 5)));
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) issue(i);
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int a = m >> 1, c = m & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (FIRST && i == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % RING][a], fb[i % RING][c], z, 0, 0, 0);
+                } else {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % RING][a], fb[i % RING][c], acc[a][c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef SF_CONV3_STAMPS_POS
+                if (m == NM - 1 && (tid & 63) == 0 && stamp_step < STAMP_STEPS && i < 20)
+                    g_pos_stamps[((blockIdx.x * STAMP_STEPS + stamp_step) * 8 + (tid >> 6)) * 20 + i] = __builtin_amdgcn_s_memtime();
+#endif
+                if (i + PF < NPOS && m < NR) read_one(i + PF, m);
+                // the copy pieces behind the position's last MFMAs
+                if (m >= NM - PPP) {
+                    const int j = i * PPP + (m - (NM - PPP));
+#ifdef SF_CONV3_DIAG_NOCOPY       // timing only: the stage buffers keep what the first copies brought
+                    if (p.N < 0)
+#endif
+                    if (j < D_NWJ + D_NPJ) issue_piece(ss, fill, j);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     };
 
     // Epilogue of an item.  The ReLU-mask loads are issued together and without branches; the
@@ -755,9 +827,6 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // whole-line streaming stores: bf16 output rows of exactly 64 channels (one 128-byte line each)
     const bool line_stores = EPI >= 2 || (RES && p.K == 64 && p.ldo == 64 && p.out_dtype == SF_BF16 &&
                                           (reinterpret_cast<uintptr_t>(p.out) & 127) == 0);
-#ifdef SF_CONV3_STAMPS
-    int stamp_step = 0;
-#endif
     ItemPos cur, nxt;
     cur.q = jblk; cur.chunk = 0;
     if (cur.q >= nitems) {
@@ -805,6 +874,11 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     constexpr int NST = 4 * MT + (EPI == 2 ? 2 : 0);
     bool after_epi = false;
     auto stage_sync = [&]() {
+#ifdef SF_CONV3_DIAG_NOBARRIER    // timing only: the waves run free of each other
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        after_epi = false;
+        return;
+#endif
 #ifndef SF_CONV3_DIAG_DRAIN
         if (SP && after_epi) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
         else
@@ -877,6 +951,11 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
 }
 
 #ifdef SF_CONV3_STAMPS
+#ifdef SF_CONV3_STAMPS_POS
+extern "C" int sf_conv3x3_read_pos_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pos_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int sf_conv3x3_read_stamps(unsigned long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }

@@ -11,6 +11,6 @@ shift
 for n in "$@"; do
   echo "== $n"
   SF_LIB=$PWD/tools/diag/libsfhip_$n.so timeout -k 10 120 python tools/res_probe.py 2>&1 | grep -v amdgpu.ids || { echo "probe $n failed"; exit 1; }
-  SF_LIB=$PWD/tools/diag/libsfhip_$n.so timeout -k 10 120 python tools/wide_probe.py 160 200 64 128 2>&1 | grep -v amdgpu.ids || { echo "probe $n failed"; exit 1; }
+  SF_LIB=$PWD/tools/diag/libsfhip_$n.so timeout -k 10 120 python tools/wide_probe.py 160 100 128 256 2>&1 | grep -v amdgpu.ids || { echo "probe $n failed"; exit 1; }
 done > gpurun_out/${TAG}_diag.txt 2>&1
 cat gpurun_out/${TAG}_diag.txt
