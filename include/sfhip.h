@@ -141,14 +141,16 @@ int sf_conv4x4s2(const void* in, const void* ws, const float* bias, const void* 
                  int IH, int IW, int C, int OH, int OW, int K, int ldo, int dgrad, int act,
                  int aux_mode, void* stream);
 
-/* Process-wide knob of sf_wgrad3x3.  dynamic = 0 (default): every workgroup streams a fixed slice
- * of the tiles and the result is bit-reproducible.  dynamic = 1: the slice is only the workgroup's
- * own list; a workgroup that has finished its list takes tiles from the lists of the others, so
- * that a workgroup which starts late or shares its CU with another kernel (RCCL's, in data-parallel
- * training) gets help instead of stretching the launch; when that happens the partition of the sums
- * differs from the fixed one (last-bit differences).  dynamic = 2: as 1, and every second workgroup
- * leaves its whole list to the others (a self-test of the stealing, for the test-suite).  No
- * counterpart in the reference (it has no data-parallel path). */
+/* Process-wide knob of sf_wgrad3x3 / sf_wgrad4x4s2.  dynamic = 0 (default): every workgroup streams
+ * a fixed slice of the tiles and the result is bit-reproducible.  dynamic = 1: tiles are dealt at run
+ * time, so that a workgroup which starts late or shares its CU with another kernel (RCCL's, in
+ * data-parallel training) does less instead of stretching the launch -- 64 x 64 blocks (layers of at
+ * most 64 output channels): the slice is the workgroup's own list and a workgroup that has finished
+ * it takes tiles from the lists of the others; 128 x 64 blocks (all other layers): the workgroups of
+ * one XCD and block draw from one queue.  The partition of the sums then differs from the fixed one
+ * (last-bit differences).  dynamic = 2: as 1, and on 64 x 64 blocks every second workgroup leaves its
+ * whole list to the others (a self-test of the stealing, for the test-suite).  No counterpart in
+ * the reference (it has no data-parallel path). */
 int sf_set_wgrad_scheduling(int dynamic);
 /*
  * Convolution weight gradients, bf16 NHWC, f32 OIHW result (overwritten):
@@ -159,6 +161,7 @@ int sf_set_wgrad_scheduling(int dynamic);
  * x [N,H,W,Cx], dout [N,OH,OW,Kd] (Cx, Kd = channel strides, multiples of 8); K, Cin = real
  * channel counts of dw.  ws: caller-provided scratch of *_workspace_bytes(...) bytes holding
  * per-slice partial sums that are reduced in a fixed order (bitwise reproducible, no atomics).
+ * One image of x and of dout must stay below 2 GiB (32-bit offsets inside an image).
  */
 size_t sf_wgrad3x3_workspace_bytes(int N, int H, int W, int K, int Cin);
 int sf_wgrad3x3(const void* x, const void* dout, float* dw, float* ws, size_t ws_bytes, int N, int H,
