@@ -29,10 +29,21 @@ import sys
 SIMDS = 1024
 
 
+def variant(name):
+    """Template instances that are different kernels in all but name keep a tag."""
+    if "wgrad_wide_kernel" in name:
+        return "<4x4s2>" if "WideCfg<true" in name else "<3x3>"
+    m = re.search(r"enc1_bwd2_kernel<\d+, (\d)>", name)
+    if m:
+        return "<gram>" if m.group(1) == "2" else "<routed>"
+    return ""
+
+
 def short(name):
+    tag = variant(name)
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)
-    return name.split("(")[0].split("<")[0]
+    return name.split("(")[0].split("<")[0] + tag
 
 
 def read_db(path, table):

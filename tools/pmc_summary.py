@@ -15,13 +15,25 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
+def variant(name):
+    """Template instances that are different kernels in all but name keep a tag."""
+    if "wgrad_wide_kernel" in name:
+        return "<4x4s2>" if "WideCfg<true" in name else "<3x3>"
+    m = re.search(r"enc1_bwd2_kernel<\d+, (\d)>", name)
+    if m:
+        return "<gram>" if m.group(1) == "2" else "<routed>"
+    return ""
+
+
 def short_name(name):
+    tag = variant(name)
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = name.replace("_ZN12_GLOBAL__N_1", "").split("(")[0]
-    return name.split("<")[0] if not name[:1].isdigit() else name
+    return (name.split("<")[0] if not name[:1].isdigit() else name) + tag
 
 
 def per_kernel_db(path, counter):
