@@ -323,10 +323,26 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     using Cf = DCfg<KT, CK>;
     constexpr int ROWB = Cf::ROWB, SLOTS = Cf::SLOTS, RPP = Cf::RPP, MT = Cf::MT, KS = Cf::KS, NPOS = Cf::NPOS;
     constexpr int D_WIMG = Cf::WIMG, D_BUF = Cf::BUF, D_WJOBS = Cf::WJOBS, D_PJOBS = Cf::PJOBS;
-    constexpr int D_NWJ = Cf::NWJ, D_NPJ = Cf::NPJ;
+    // LOADERS (the wide plain variant): the copies of a stage are issued by waves 4-7 alone, all of them
+    // at the start of the stage.  Those waves lose the matrix pipe to their older partners on the SIMD for
+    // the first half of a stage anyway (issue arbitration goes by age), so the ~100 cycles each copy
+    // instruction holds its wave cost them nothing there, while waves 0-3 run their MFMAs without a
+    // single copy in their stream and waves 4-7 find none left when they have the pipe to themselves.
+#ifdef SF_CONV3_NO_LOADERS
+    constexpr bool LOADERS = false;
+#else
+    constexpr bool LOADERS = EPI == 1;
+#endif
+    constexpr int JW = LOADERS ? 4 : 8;          // waves that issue copies
+    constexpr int D_NWJ = (D_WJOBS + JW - 1) / JW, D_NPJ = (D_PJOBS + JW - 1) / JW;
     extern __shared__ __attribute__((aligned(16))) char smd[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SF_CONV3_LOADERS_FIRST_HALF     // comparison build: waves 0-3 copy instead
+    const int jw = LOADERS ? (wave < 4 ? wave : -1) : wave;
+#else
+    const int jw = LOADERS ? wave - 4 : wave;    // index among the copying waves (negative: none)
+#endif
     const int r = lane & 31, h = lane >> 5;
     const int PW = p.TW + 2, PP = (p.TH + 2) * PW, TP = p.TH * p.TW;
 
@@ -355,14 +371,13 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // ---- DMA jobs (tile-invariant part).  A job fills RPP consecutive rows: lane l writes slot
     // l % SLOTS of row l / SLOTS and fetches the channel chunk slot ^ swz(row).
     const int jrow = lane / SLOTS, jslot = lane % SLOTS;
-    int w_rel[D_NWJ], w_k[D_NWJ];
-    (void)w_k;
+    // (LOADERS takes staged weights only -- the host sees to it --, whose copy offsets need no table)
+    int w_rel[LOADERS ? 1 : D_NWJ];
 #pragma unroll
-    for (int i = 0; i < D_NWJ; ++i) {
+    for (int i = 0; i < (LOADERS ? 0 : D_NWJ); ++i) {
         const int row = RPP * (wave + 8 * i) + jrow;         // t * KT + k
         const int t = row / KT, k = row % KT;
         const int wch = jslot ^ Cf::swz(row);                    // channel chunk of the stage
-        w_k[i] = k;
         w_rel[i] = ((k * 9 + t) * p.C + (wch << 3)) * 2;          // bytes
         if ((wch << 3) >= p.C) w_rel[i] = -1;                    // C < 32: beyond the tensor -> zeros
         if (p.wstaged) w_rel[i] = (wave + 8 * i) * 1024 + lane * 16;   // the image itself, in copy order
@@ -370,7 +385,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     int p_rel[D_NPJ], p_pyx[D_NPJ];
 #pragma unroll
     for (int i = 0; i < D_NPJ; ++i) {
-        const int row = RPP * (wave + 8 * i) + jrow;         // patch pixel
+        const int row = RPP * ((jw < 0 ? 0 : jw) + JW * i) + jrow;         // patch pixel
         const int py = row / PW, px = row - py * PW;
         const int pch = jslot ^ Cf::swz(row);
         p_pyx[i] = (row < PP && (pch << 3) < p.C) ? ((py << 16) | px) : -1;
@@ -412,17 +427,20 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     };
     // piece j of a stage's copy: j < D_NWJ weights, then the patch
     auto issue_wpiece = [&](const StageSrc& ss, char* dst, int j) {
-        const int job = wave + 8 * j;
-        if (D_WJOBS % 8 == 0 || job < D_WJOBS)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(dst + job * 1024), 16, w_rel[j], 0, 0, 0);
+        if (LOADERS && jw < 0) return;
+        const int job = jw + JW * j;
+        if (D_WJOBS % JW == 0 || job < D_WJOBS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(dst + job * 1024), 16,
+                                                     LOADERS ? job * 1024 + lane * 16 : w_rel[j], 0, 0, 0);
     };
     constexpr int P_OFF = RES ? 0 : D_WIMG;      // patch image inside a stage buffer
     auto issue_piece = [&](const StageSrc& ss, char* buf, int j) {
+        if (LOADERS && jw < 0) return;
         if (j < D_NWJ) {
             if (!RES) issue_wpiece(ss, buf, j);
         } else {
-            const int i = j - D_NWJ, job = wave + 8 * i;
-            if (D_PJOBS % 8 == 0 || job < D_PJOBS) {
+            const int i = j - D_NWJ, job = jw + JW * i;
+            if (D_PJOBS % JW == 0 || job < D_PJOBS) {
                 const int gy = ss.ym1 + (p_pyx[i] >> 16), gx = ss.xm1 + (p_pyx[i] & 0xffff);
                 const bool ok = p_pyx[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
                 const int voff = ok ? ss.ioff + p_rel[i] : (int)0x80000000;
@@ -572,6 +590,13 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
         };
 #pragma unroll
         for (int i = 0; i < PF; ++i) issue(i);
+        if (LOADERS) {
+#ifdef SF_CONV3_DIAG_NOCOPY
+            if (p.N < 0)
+#endif
+#pragma unroll
+            for (int j = 0; j < D_NWJ + D_NPJ; ++j) issue_piece(ss, fill, j);
+        }
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
 #pragma unroll
@@ -593,7 +618,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
 #endif
                 if (i + PF < NPOS && m < NR) read_one(i + PF, m);
                 // the copy pieces behind the position's last MFMAs
-                if (m >= NM - PPP) {
+                if (!LOADERS && m >= NM - PPP) {
                     const int j = i * PPP + (m - (NM - PPP));
 #ifdef SF_CONV3_DIAG_NOCOPY       // timing only: the stage buffers keep what the first copies brought
                     if (p.N < 0)
@@ -1004,7 +1029,7 @@ template <int KT, int CK, bool RES = false> int launch3_dma(const C3Params& q, h
                        (reinterpret_cast<uintptr_t>(p.out) & 127) == 0;
     int epi = 0;
     if (!RES && KT == 128 && bf16_groups && p.K % KT == 0 && !p.bias && p.act == SF_ACT_NONE && !p.aux_mode &&
-        p.ldo % 64 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 127) == 0)
+        p.ldo % 64 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 127) == 0 && p.wstaged)
         epi = 1;
     if (RES && lines && p.bias && p.act == SF_ACT_RELU && !p.aux_mode && p.dot_out) epi = 2;
     if (RES && lines && !p.bias && p.act == SF_ACT_NONE && p.aux_mode == 1 && !p.dot_out) epi = 3;
