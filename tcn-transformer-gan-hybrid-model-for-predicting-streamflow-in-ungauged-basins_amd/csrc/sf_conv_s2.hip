@@ -29,10 +29,21 @@ constexpr int KT = 128, CK = 16, ROWB = CK * 2, SLOTS = ROWB / 16, RPP = 1024 / 
 constexpr int NTAP = 4, WTOT = 16;                       // taps per stage; taps per packed weight row
 constexpr int WIMG = NTAP * KT * ROWB, PIMG = S_PP * ROWB, BUF = WIMG + PIMG;
 constexpr int WJOBS = WIMG / 1024, PJOBS = PIMG / 1024;
-constexpr int NWJ = (WJOBS + 7) / 8, NPJ = (PJOBS + 7) / 8, NPIECE = NWJ + NPJ;
+// The copies of a stage are issued by waves 4-7 alone, all of them at the start of the stage: those waves
+// lose the matrix pipe to their older partners on the SIMD for the first half of a stage anyway (issue
+// arbitration goes by age), so the ~100 cycles each copy instruction holds its wave cost them nothing
+// there, waves 0-3 run their MFMAs without a copy in their stream, and waves 4-7 find none left when they
+// have the pipe to themselves.  (SF_CONV_S2_NO_LOADERS: every wave copies, spread over the taps.)
+#ifdef SF_CONV_S2_NO_LOADERS
+constexpr bool LOADERS = false;
+#else
+constexpr bool LOADERS = true;
+#endif
+constexpr int JW = LOADERS ? 4 : 8;                       // waves that issue copies
+constexpr int NWJ = (WJOBS + JW - 1) / JW, NPJ = (PJOBS + JW - 1) / JW, NPIECE = NWJ + NPJ;
 constexpr int MT = KT / 32, NPOS = NTAP;
 constexpr int PPP = (NPIECE + NPOS - 1) / NPOS;          // copy pieces issued per tap position
-static_assert(WJOBS % 8 == 0, "every wave copies the same number of weight pieces");
+static_assert(WJOBS % JW == 0, "every copying wave copies the same number of weight pieces");
 
 __device__ __forceinline__ int swz(int row) { return (row >> 3) & 1; }
 
@@ -108,13 +119,12 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
     const int jrow = lane / SLOTS, jslot = lane % SLOTS;
     // the weights arrive as the stages' LDS images (sf_conv4x4s2_stage_weights): every copy piece
     // reads 1 KiB of contiguous memory
-    int w_rel[NWJ];
-#pragma unroll
-    for (int i = 0; i < NWJ; ++i) w_rel[i] = (wave + 8 * i) * 1024 + lane * 16;   // bytes
+    const int jw = LOADERS ? wave - 4 : wave;            // index among the copying waves (negative: none)
+    const int jw0 = jw < 0 ? 0 : jw;
     int p_rel[NPJ], p_pyx[NPJ];
 #pragma unroll
     for (int i = 0; i < NPJ; ++i) {
-        const int row = RPP * (wave + 8 * i) + jrow;         // patch pixel
+        const int row = RPP * (jw0 + JW * i) + jrow;         // patch pixel
         const int py = row / PW, px = row - py * PW;
         const int pch = jslot ^ swz(row);
         p_pyx[i] = row < PP ? ((py << 16) | px) : -1;
@@ -144,14 +154,15 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
         return ss;
     };
     auto issue_piece = [&](const StageSrc& ss, char* buf, int j) {
+        if (LOADERS && jw < 0) return;
         if (j < NWJ) {
-            const int job = wave + 8 * j;
+            const int job = jw + JW * j;
             // a piece is 32 rows of the image: rows t * 128 + k, so pieces 4 t + 2, 4 t + 3 hold k >= 64
             if (MTU == MT || (job & 3) < 2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(buf + job * 1024), 16, w_rel[j], 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(buf + job * 1024), 16, job * 1024 + lane * 16, 0, 0, 0);
         } else if (j < NPIECE) {
-            const int i = j - NWJ, job = wave + 8 * i;
-            if (PJOBS % 8 == 0 || job < PJOBS) {
+            const int i = j - NWJ, job = jw + JW * i;
+            if (PJOBS % JW == 0 || job < PJOBS) {
                 const int gy = ss.oy + IS * (p_pyx[i] >> 16), gx = ss.ox + IS * (p_pyx[i] & 0xffff);
                 const bool ok = p_pyx[i] >= 0 && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW;
                 const int voff = ok ? ss.ioff + p_rel[i] : (int)0x80000000;     // out of range -> zeros
@@ -204,11 +215,17 @@ __device__ __forceinline__ void conv_s2_body(const S2Params& p) {
             for (int c = 0; c < 2; ++c) fb[s][c] = *reinterpret_cast<const bf16x8*>(pl + pa[c][i]);
         };
         issue(0);
+        if (LOADERS) {
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) issue_piece(ss, fill, j);
+        }
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
             if (i + 1 < NPOS) issue(i + 1);
+            if (!LOADERS) {
 #pragma unroll
-            for (int j = i * PPP; j < (i + 1) * PPP; ++j) issue_piece(ss, fill, j);
+                for (int j = i * PPP; j < (i + 1) * PPP; ++j) issue_piece(ss, fill, j);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < MTU; ++a)
