@@ -323,7 +323,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     using Cf = DCfg<KT, CK>;
     constexpr int ROWB = Cf::ROWB, SLOTS = Cf::SLOTS, RPP = Cf::RPP, MT = Cf::MT, KS = Cf::KS, NPOS = Cf::NPOS;
     constexpr int D_WIMG = Cf::WIMG, D_BUF = Cf::BUF, D_WJOBS = Cf::WJOBS, D_PJOBS = Cf::PJOBS;
-    // LOADERS (the wide plain variant): the copies of a stage are issued by waves 4-7 alone, all of them
+    // LOADERS (the fixed-epilogue variants): the copies of a stage are issued by waves 4-7 alone, all of them
     // at the start of the stage.  Those waves lose the matrix pipe to their older partners on the SIMD for
     // the first half of a stage anyway (issue arbitration goes by age), so the ~100 cycles each copy
     // instruction holds its wave cost them nothing there, while waves 0-3 run their MFMAs without a
@@ -331,7 +331,7 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
 #ifdef SF_CONV3_NO_LOADERS
     constexpr bool LOADERS = false;
 #else
-    constexpr bool LOADERS = EPI == 1;
+    constexpr bool LOADERS = EPI != 0;
 #endif
     constexpr int JW = LOADERS ? 4 : 8;          // waves that issue copies
     constexpr int D_NWJ = (D_WJOBS + JW - 1) / JW, D_NPJ = (D_PJOBS + JW - 1) / JW;
@@ -371,17 +371,21 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     // ---- DMA jobs (tile-invariant part).  A job fills RPP consecutive rows: lane l writes slot
     // l % SLOTS of row l / SLOTS and fetches the channel chunk slot ^ swz(row).
     const int jrow = lane / SLOTS, jslot = lane % SLOTS;
-    // (LOADERS takes staged weights only -- the host sees to it --, whose copy offsets need no table)
-    int w_rel[LOADERS ? 1 : D_NWJ];
-#pragma unroll
-    for (int i = 0; i < (LOADERS ? 0 : D_NWJ); ++i) {
-        const int row = RPP * (wave + 8 * i) + jrow;         // t * KT + k
+    // byte offset of this lane's 16 bytes of weight copy job `job`
+    auto w_off = [&](int job) {
+        if (p.wstaged) return job * 1024 + lane * 16;           // the image itself, in copy order
+        const int row = RPP * job + jrow;                        // t * KT + k
         const int t = row / KT, k = row % KT;
         const int wch = jslot ^ Cf::swz(row);                    // channel chunk of the stage
-        w_rel[i] = ((k * 9 + t) * p.C + (wch << 3)) * 2;          // bytes
-        if ((wch << 3) >= p.C) w_rel[i] = -1;                    // C < 32: beyond the tensor -> zeros
-        if (p.wstaged) w_rel[i] = (wave + 8 * i) * 1024 + lane * 16;   // the image itself, in copy order
-    }
+        return (wch << 3) >= p.C ? -1 : ((k * 9 + t) * p.C + (wch << 3)) * 2;   // C < 32: beyond the tensor -> zeros
+    };
+    // The streamed shapes keep the offsets of their jobs in registers; the resident shape copies its
+    // weights once, by all eight waves, and computes them on the spot; with loader waves the weights
+    // are staged (the host sees to it) and the offset is two operations.
+    constexpr bool W_TABLE = !RES && !LOADERS;
+    int w_rel[W_TABLE ? D_NWJ : 1];
+#pragma unroll
+    for (int i = 0; i < (W_TABLE ? D_NWJ : 0); ++i) w_rel[i] = w_off(wave + 8 * i);
     int p_rel[D_NPJ], p_pyx[D_NPJ];
 #pragma unroll
     for (int i = 0; i < D_NPJ; ++i) {
@@ -427,6 +431,12 @@ __device__ __forceinline__ void conv3_dma_body(const C3DParams& p) {
     };
     // piece j of a stage's copy: j < D_NWJ weights, then the patch
     auto issue_wpiece = [&](const StageSrc& ss, char* dst, int j) {
+        if (RES) {          // once per kernel: every wave takes part (j < ceil(jobs / 8))
+            const int job = wave + 8 * j;
+            if (job < D_WJOBS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ss.wrs, (lptr_t)(dst + job * 1024), 16, w_off(job), 0, 0, 0);
+            return;
+        }
         if (LOADERS && jw < 0) return;
         const int job = jw + JW * j;
         if (D_WJOBS % JW == 0 || job < D_WJOBS)
