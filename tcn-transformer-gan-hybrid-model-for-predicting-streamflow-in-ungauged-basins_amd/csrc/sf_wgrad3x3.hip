@@ -566,8 +566,13 @@ template <bool S2_, int TP_, int PP_, int NB_> struct WideCfg {
     static constexpr int BUF = 4 * DQ + 2 * XH;
     static constexpr int NSTEPS = TP / 16;
     static constexpr int ND = 4 * TP / 16, NX = 2 * PP / 16;     // copy jobs (1 KB each) per tile
-    static constexpr int J = (ND + NX) / 8;                        // per wave
-    static_assert((ND + NX) % 8 == 0, "copy jobs must divide over the eight waves");
+#ifdef SF_WIDE_NO_LOADERS
+    static constexpr int JWV = 8;                                  // waves that issue the copies
+#else
+    static constexpr int JWV = 4;                                  // waves 4-7 (see the kernel)
+#endif
+    static constexpr int J = (ND + NX) / JWV;                      // per copying wave
+    static_assert((ND + NX) % JWV == 0, "copy jobs must divide over the copying waves");
     static_assert(NB * BUF + 16 <= 160 * 1024, "ring exceeds LDS");
     static_assert((NB - 1) * J < 64, "vmcnt counts 63 at most");
 };
@@ -615,14 +620,19 @@ __global__ __launch_bounds__(NTW, 2) void wgrad_wide_kernel(WPParams p) {
     const int PP = PH * PW, TP = p.TH * p.TW;
     constexpr int RM = S2 ? 2 : 1;          // input rows between two patch rows
 
-    // ---- copy jobs of this wave (tile-invariant part).  Job j = wave + 8 i: the first ND jobs fill
-    // dOut (quarter j & 3, row group j >> 2), the others the input (half, row group).
+    // ---- copy jobs of this wave (tile-invariant part).  The copies are issued by waves 4-7 alone: they
+    // lose the matrix pipe to their older partners on the SIMD (waves 0-3) at the start of a tile
+    // anyway, so the ~100 cycles a copy instruction holds its wave cost them nothing there, and waves
+    // 0-3 start their MFMAs at once.  Job j = jw + JWV i: the first ND jobs fill dOut (quarter j & 3,
+    // row group j >> 2), the others the input (half, row group).
+    constexpr int JWV = G::JWV;
+    const int jw = JWV == 4 ? wave - 4 : wave;           // index among the copying waves (negative: none)
     const int jrow = lane >> 2, jch = (lane & 3) * 8;
     int j_pyx[J], j_rel[J], j_dst[J];
     bool j_isx[J];
 #pragma unroll
     for (int i = 0; i < J; ++i) {
-        const int j = wave + 8 * i;
+        const int j = (jw < 0 ? 0 : jw) + JWV * i;
         j_isx[i] = j >= G::ND;
         if (!j_isx[i]) {
             const int dq = j & 3, g = j >> 2;
@@ -646,6 +656,7 @@ __global__ __launch_bounds__(NTW, 2) void wgrad_wide_kernel(WPParams p) {
     }
 
     auto issue_tile = [&](int tile, char* lbase) __attribute__((always_inline)) {
+        if (jw < 0) return;
         const bool live = tile < p.ntiles;
         if (!live) tile = 0;
         const int txi = tile % p.tiles_x;
