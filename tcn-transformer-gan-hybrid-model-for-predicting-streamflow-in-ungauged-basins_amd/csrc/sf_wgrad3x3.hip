@@ -274,20 +274,29 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
 
     // ---- DMA jobs of this wave (tile-invariant part).  Job = 16 rows of one image half.
     // dOut halves: 16 row groups each, this wave fills half (wave & 1), groups (wave >> 1) + 4 i.
-    constexpr int NDJ = G_TP / 16 / 4, NXJ = G_PP / 16 / 4;
-    const int jhalf = wave & 1, jg0 = wave >> 1;
+    // (issued by waves 4-7 alone, which lose the matrix pipe to waves 0-3 at the start of a tile anyway:
+    // half jw & 1, row groups (jw >> 1) + 2 i; SF_WGRAD3_NO_LOADERS: all eight waves, groups (wave >> 1) + 4 i)
+#ifdef SF_WGRAD3_NO_LOADERS
+    constexpr int GSTEP = 4;
+    const int jw = wave;
+#else
+    constexpr int GSTEP = 2;
+    const int jw = wave - 4;
+#endif
+    constexpr int NDJ = G_TP / 16 / GSTEP, NXJ = G_PP / 16 / GSTEP;
+    const int jhalf = jw & 1, jg0 = (jw < 0 ? 0 : jw) >> 1;
     const int jrow = lane >> 2, jcol = jhalf * 32 + (lane & 3) * 8;  // row in the group, channel
     int d_lyx[NDJ], d_rel[NDJ], x_pyx[NXJ], x_rel[NXJ];
 #pragma unroll
     for (int i = 0; i < NDJ; ++i) {
-        const int pix = 16 * (jg0 + 4 * i) + jrow;
+        const int pix = 16 * (jg0 + GSTEP * i) + jrow;
         const int ly = pix / p.TW, lx = pix - ly * p.TW;
         d_lyx[i] = pix < TP ? ((ly << 16) | lx) : -1;
         d_rel[i] = ((ly * p.OW + lx) * p.Kd + kt * 64 + jcol) * 2;   // bytes
     }
 #pragma unroll
     for (int i = 0; i < NXJ; ++i) {
-        const int pp = 16 * (jg0 + 4 * i) + jrow;
+        const int pp = 16 * (jg0 + GSTEP * i) + jrow;
         const int py = pp / PW, px = pp - py * PW;
         x_pyx[i] = pp < PP ? ((py << 16) | px) : -1;
         x_rel[i] = ((py * p.IW + px) * p.Cx + ct * 64 + jcol) * 2;   // bytes
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
     // offsets are 32-bit bytes, and an offset past the buffer's end writes zeros (padding,
     // pixels outside the tile, channels beyond the tensor).
     auto issue_tile = [&](int tile, char* lbase) __attribute__((always_inline)) {
+        if (jw < 0) return;
         const int txi = tile % p.tiles_x;
         const int rest = tile / p.tiles_x;
         const int tyi = rest % p.tiles_y;
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
             const int ly = d_lyx[i] >> 16, lx = d_lyx[i] & 0xffff;
             const bool ok = d_lyx[i] >= 0 && d_col_ok && oy0 + ly < p.OH && ox0 + lx < p.OW;
             const int voff = ok ? doff + d_rel[i] : (int)0x80000000;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lptr_t)(lbase + lds_d0 + i * 4096), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lptr_t)(lbase + lds_d0 + i * GSTEP * 1024), 16, voff, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NXJ; ++i) {
@@ -327,8 +337,8 @@ __global__ __launch_bounds__(NTW, 2) void wgrad3_dma_kernel(WPParams p) {
             const bool ok = x_pyx[i] >= 0 && x_col_ok && gy >= 0 && gy < p.IH && gx >= 0 && gx < p.IW;
             const int voff = ok ? xoff + x_rel[i] : (int)0x80000000;
             // patch rows 368 .. 383 lie beyond the patch when tiles can be stolen, and carry the four words of the hand-over
-            if (STEAL && i == NXJ - 1 && jg0 == 3) continue;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(lbase + lds_x0 + i * 4096), 16, voff, 0, 0, 0);
+            if (STEAL && jg0 + GSTEP * i == G_PP / 16 - 1) continue;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(lbase + lds_x0 + i * GSTEP * 1024), 16, voff, 0, 0, 0);
         }
     };
 

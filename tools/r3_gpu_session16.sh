@@ -10,7 +10,7 @@ grep -q "rc=0" gpurun_out/${TAG}_tests.log || { tail -n 60 gpurun_out/${TAG}_tes
 shift
 for n in "$@"; do
   echo "== $n"
-  SF_LIB=$PWD/tools/diag/libsfhip_$n.so timeout -k 10 120 python tools/wgrad_probe.py 160,100,128,256 2>&1 | grep -v amdgpu.ids | cut -c1-120 || { echo "probe $n failed"; exit 1; }
+  SF_LIB=$PWD/tools/diag/libsfhip_$n.so timeout -k 10 120 python tools/wgrad_probe.py 32,400,64,64 2>&1 | grep -v amdgpu.ids | cut -c1-120 || { echo "probe $n failed"; exit 1; }
   SF_LIB=$PWD/tools/diag/libsfhip_$n.so timeout -k 10 120 python tools/s2_probe.py 2>&1 | grep -o "^[0-9x]* [0-9>-]*\|wgrad.*" | paste - - || { echo "probe $n failed"; exit 1; }
 done > gpurun_out/${TAG}_diag.txt 2>&1
 cat gpurun_out/${TAG}_diag.txt
