@@ -54,6 +54,7 @@ for (IH, C, K) in ((200, 64, 128), (100, 128, 256), (50, 256, 512)):
 
     t_dold = timeit(old_dgrad)
     t_wg = timeit(lambda: ops.wgrad4x4s2(x, dz, dw))
+    t_dmask = timeit(lambda: ops.conv4x4s2(dz, wT, dx, C, dgrad=True, aux=x, aux_mode=2))
     print(f"{IH}x{IH} {C}->{K}: fwd {t_new * 1e3:.0f} us ({fl / t_new / 1e9:.0f} TF/s) vs generic {t_old * 1e3:.0f} us; "
           f"dgrad {t_dnew * 1e3:.0f} us ({fl / t_dnew / 1e9:.0f} TF/s) vs generic {t_dold * 1e3:.0f} us; "
-          f"wgrad {t_wg * 1e3:.0f} us ({fl / t_wg / 1e9:.0f} TF/s)", flush=True)
+          f"wgrad {t_wg * 1e3:.0f} us ({fl / t_wg / 1e9:.0f} TF/s); masked dgrad {t_dmask * 1e3:.0f} us", flush=True)
