@@ -218,7 +218,8 @@ def main():
     # kernel are bracketed (2 per step: the encoder's second conv and its data gradient); the other
     # MFMA kernels are timed in extra steps after it
     dom = "conv3_dma_wide_kernel"
-    other_tags = ("conv3_dma_res_kernel", "conv3_dma_res_mask_kernel", "conv3_dma_kernel", "wgrad3_dma_kernel")
+    other_tags = ("conv3_dma_res_kernel", "conv3_dma_res_mask_kernel", "conv3_dma_kernel", "wgrad_wide_kernel",
+                  "wgrad3_dma_kernel")
     ops.TIMED[dom] = []
     if exchanging:
         trainer.comm_events = []
@@ -306,8 +307,8 @@ def main():
         # The three MFMA kernels of the 3x3 convolutions, every launch timed with HIP events on the
         # launch stream; algorithmic flops of a launch = 2 * N*H*W * Cin * Cout * 9 with the real
         # channel counts.  conv3_dma_wide_kernel / conv3_dma_kernel / conv3_dma_res_kernel / conv3_dma_res_mask_kernel are the
-        # shapes of the persistent forward / data-gradient kernel (res: weights resident in LDS), wgrad3_dma_kernel the weight gradient (its
-        # event pair also spans the small slab-reduction launch that follows it).
+        # shapes of the persistent forward / data-gradient kernel (res: weights resident in LDS), wgrad_wide_kernel (more than 64 output channels) and wgrad3_dma_kernel the weight
+        # gradient (their event pairs also span the small slab-reduction launch that follows).
         n_l, ms_l, achieved = dom_stats
         traffic_row, traffic_src = profile_row(PMC_TRAFFIC, dom)
         mfma_row, mfma_src = profile_row(PMC_MFMA, dom)

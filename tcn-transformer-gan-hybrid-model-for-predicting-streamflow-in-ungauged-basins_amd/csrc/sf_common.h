@@ -180,9 +180,14 @@ __device__ __forceinline__ int queue_take_async(WorkQueue* q, int h) {
     return ticket;
 }
 // Makes the ticket of queue_take_async readable: waits for the wave's outstanding vector-memory
-// operations and ties the wait to the ticket's register, so that the compiler can neither read,
-// copy nor spill the register's final value before the wait.  Free right behind a barrier that
-// the wave entered with its copies landed.
+// operations and ties the wait to the ticket's register, so that the compiler does not read the
+// value before the wait.  Free right behind a barrier that the wave entered with its copies
+// landed.  What the constraint cannot forbid is a register COPY or SPILL of the ticket between
+// the two calls: the atomic's result then lands in a register the compiler has given to
+// something else (a build that spilled in such a kernel faulted with an illegal address).  The
+// kernels that draw tickets therefore must build without spills and keep the ticket in a
+// variable that lives across nothing but the stage loop; tests/test_build_no_spills.py compiles
+// them with the resource remarks on and fails on any spill.
 __device__ __forceinline__ int queue_ticket_wait(int ticket) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket));
     return ticket;

@@ -422,7 +422,8 @@ def wgrad3x3(x, dout, dw, tag=None):
         _dev(x, dout, dw)
         nbytes = int(lib().sf_wgrad3x3_workspace_bytes(N, H, W, K, Cin))
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-        rec = TIMED.get(tag if tag is not None else "wgrad3_dma_kernel")
+        # same rule as sf_wgrad3x3's choice of block shape
+        rec = TIMED.get(tag if tag is not None else ("wgrad_wide_kernel" if K > 64 else "wgrad3_dma_kernel"))
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
