@@ -56,7 +56,12 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 }
 
 // Few channels (Cpad <= 16, bf16): a thread converts 4 consecutive pixels -- one float4 load per
-// channel (a wave reads 1 KB runs of each channel plane), 4 x Cpad contiguous bf16 out.
+// channel (a wave reads 1 KB runs of each channel plane), 4 x Cpad contiguous bf16 out.  The
+// output of a wave is one contiguous run (the NHWC offset is linear in the global pixel index), but
+// a thread's own 16-byte pieces sit 4 x Cpad x 2 bytes from its neighbour's: stored directly, every
+// store instruction touches 64 different lines.  The pieces therefore pass through a per-wave LDS
+// slice (9 slots per thread: the odd stride spreads the 16-byte writes over the banks) and leave
+// as whole kilobytes, lane l writing piece l of each.
 // CR > 0: the real channel count at compile time (only those planes are loaded); CR = 0: C at run
 // time, padding channels re-read plane 0 and discard it.
 template <int CP, int CR>
@@ -64,9 +69,12 @@ __global__ __launch_bounds__(NT) void nchw_to_nhwc_px4_kernel(const float* __res
                                                               unsigned nquads, int Crun, unsigned HW, int* __restrict__ flag) {
     // flag (may be null): *flag |= 1 when a loaded element is Inf or NaN -- the input check of
     // src/train.py:193 rides on the layout pass instead of reading the images a second time
+    constexpr int PPT = 4 * CP / 8;          // 16-byte pieces per thread
+    __shared__ uint4 sm[NT / 64][64 * 9];
+    static_assert(PPT <= 8, "nine slots per thread hold at most eight pieces");
     const int C = CR ? CR : Crun;
-    const unsigned q = blockIdx.x * NT + threadIdx.x;
-    if (q >= nquads) return;
+    const unsigned q0 = blockIdx.x * NT + threadIdx.x;
+    const unsigned q = q0 < nquads ? q0 : nquads - 1;      // lanes past the end load the last quad and store nothing
     const unsigned pix = q * 4, n = pix / HW, hw = pix - n * HW;
     const float* src = in + (size_t)n * C * HW + hw;
     float4 v[CP];
@@ -87,6 +95,8 @@ __global__ __launch_bounds__(NT) void nchw_to_nhwc_px4_kernel(const float* __res
         }
         if (__any(top >= 0x7f800000u) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* mine = &sm[wave][0];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -94,8 +104,20 @@ __global__ __launch_bounds__(NT) void nchw_to_nhwc_px4_kernel(const float* __res
             float f[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = c0 + e < C ? (&v[c0 + e].x)[k] : 0.f;
-            store_chunk<bf16>(out + ((size_t)pix + k) * CP + c0, f);
+            store_chunk<bf16>(reinterpret_cast<bf16*>(mine + lane * 9 + k * (CP / 8) + c0 / 8), f);
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the wave's run of pieces starts at its first quad; piece idx of the run belongs to thread idx / PPT
+    const size_t first = (size_t)(blockIdx.x * NT + wave * 64) * PPT, total = (size_t)nquads * PPT;
+    uint4* o16 = reinterpret_cast<uint4*>(out);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int idx = j * 64 + lane;
+        const uint4 piece = mine[(idx / PPT) * 9 + idx % PPT];
+        if (first + idx < total) o16[first + idx] = piece;
     }
 }
 
