@@ -346,6 +346,14 @@ int sf_dconv1_bwd_data(const void* dz, int dtype, const float* w, float* dx, int
 /* dw f32 [K,1,4,4], db f32 [K] (both zeroed here, accumulated with atomics) */
 int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, float* dw, float* db, int N,
                          int H, int W, int K, void* stream);
+/* The same gradients (src/model/gan.py:37-41 under loss.backward()) with a caller-provided
+ * workspace of sf_dconv1_bwd_weight_workspace_bytes(N, H, W, K) bytes (0 when the shape has no
+ * use for one): per-workgroup partial sums stored there and added in a fixed order instead of
+ * atomics (bit-reproducible, and the atomics' contention was most of the pass).  ws may be null:
+ * then this is sf_dconv1_bwd_weight. */
+size_t sf_dconv1_bwd_weight_workspace_bytes(int N, int H, int W, int K);
+int sf_dconv1_bwd_weight_ws(const float* x, const void* dz, int dtype, float* dw, float* db,
+                            float* ws, size_t ws_bytes, int N, int H, int W, int K, void* stream);
 /* Single-output-channel conv: Conv2d(C,1,R,s1,pad)+bias (src/model/gan.py:48-51 with R=4,pad=1;
  * src/model/decoder.py:152 with R=1,pad=0).  x NHWC dtype [N,H,W,C]; w f32 [1,Creal,R,R];
  * y f32 [N,1,OH,OW]. */

@@ -322,20 +322,30 @@ __global__ __launch_bounds__(NT) void dconv1_fwd_mfma_kernel(const float* __rest
 
 // [dw | db][tap or bias row][channel] = A[row][pixel] * dz[pixel][channel] with the pixels as the
 // reduction: rows 0..15 of A are the taps of the pixel's patch, row 16 is all ones (bias
-// gradient), the rest zero.  Lane (r, h) covers the run of 8 pixels 8h..8h+7 of a 16-pixel group
-// (OW % 8 == 0 keeps a run inside one output row): 8 x loads for tap r, and 8 dword loads of
-// channels (2r, 2r+1) whose low / high halves feed two MFMAs (columns = even / odd channels).
+// gradient), the rest zero.  Lane (r, h) covers the run of 8 consecutive pixels 8h..8h+7 of a
+// 16-pixel group: 8 x loads for tap r, and 8 dword loads of channels (2r, 2r+1) whose low / high
+// halves feed two MFMAs (columns = even / odd channels).  CROSS = false: OW % 8 == 0, a run stays
+// inside one output row.  CROSS = true (OW >= 8): a run may cross into the next output row or
+// image (at most once) and the last run may end before its eighth pixel; a pixel past the end
+// reads pixel M - 1 against a zero column of A.
+// Results: with `slab` every workgroup stores its 17 x 64 sums to row blockIdx.x of it and
+// dconv1_wfold_kernel adds the rows in order (the 256 x 1088 atomics of the other form all land
+// on 70 cache lines at the same moment and took longer than the pass itself); without, atomics
+// into the zeroed dw / db.
 constexpr int WG_NT = 512;
+template <bool CROSS>
 __global__ __launch_bounds__(WG_NT) void dconv1_bwd_weight_mfma_kernel(const float* __restrict__ x,
                                                                     const bf16* __restrict__ dz,
                                                                     float* __restrict__ dw, float* __restrict__ db,
+                                                                    float* __restrict__ slab,
                                                                     unsigned M, int H, int W, int OH, int OW) {
     constexpr int U = 2;
     __shared__ float sm[WG_NT / 64][17][64];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     const unsigned wave = blockIdx.x * (WG_NT / 64) + wv, nwaves = gridDim.x * (WG_NT / 64);
     const int t = r & 15, ty = t >> 2, tx = t & 3;
-    const unsigned nruns = M >> 3, ngroups = (nruns + 1) >> 1;
+    const unsigned nruns = (M + 7) >> 3, ngroups = (nruns + 1) >> 1;
+    const int nimg = (int)(M / ((unsigned)OH * OW));
     f32x16 acc[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -344,27 +354,47 @@ __global__ __launch_bounds__(WG_NT) void dconv1_bwd_weight_mfma_kernel(const flo
     for (unsigned g = wave * U; g < ngroups; g += nwaves * U) {
         float xv[U][8];
         unsigned d[U][8];
-        unsigned xok[U] = {};
-        bool lv[U];  // a dead run multiplies (valid, finite) dz of pixel 0 by a zero A column
+        unsigned xok[U] = {};      // bit j: the tap of pixel j lies inside the image; bit 8 + j: pixel j exists
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned run = (g + u) * 2 + h;
-            const bool live = run < nruns;
-            const unsigned m0 = live ? run * 8 : 0;
+            const bool rlive = run < nruns;
+            const unsigned m0 = rlive ? run * 8 : 0;
             const unsigned q = m0 / (unsigned)OW, ow0 = m0 - q * OW;
-            const unsigned n = q / (unsigned)OH, oh = q - n * OH;
-            const int iy = (int)oh * 2 - 1 + ty;
-            const bool rok = iy >= 0 && iy < H;
-            const float* xrow = x + ((size_t)n * H + min(max(iy, 0), H - 1)) * W;
-            const bf16* dzp = dz + (size_t)m0 * 64 + 2 * r;
+            const unsigned n0 = q / (unsigned)OH, oh0 = q - n0 * OH;
+            if (!CROSS) {
+                const int iy = (int)oh0 * 2 - 1 + ty;
+                const bool rok = rlive && iy >= 0 && iy < H;
+                const float* xrow = x + ((size_t)n0 * H + min(max(iy, 0), H - 1)) * W;
+                const bf16* dzp = dz + (size_t)m0 * 64 + 2 * r;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ix = ((int)ow0 + j) * 2 - 1 + tx;
-                xv[u][j] = xrow[min(max(ix, 0), W - 1)];
-                xok[u] |= (unsigned)(rok && ix >= 0 && ix < W) << j;
-                d[u][j] = *reinterpret_cast<const unsigned*>(dzp + j * 64);
+                for (int j = 0; j < 8; ++j) {
+                    const int ix = ((int)ow0 + j) * 2 - 1 + tx;
+                    xv[u][j] = xrow[min(max(ix, 0), W - 1)];
+                    xok[u] |= (unsigned)(rok && ix >= 0 && ix < W) << j;
+                    d[u][j] = *reinterpret_cast<const unsigned*>(dzp + j * 64);
+                }
+                xok[u] |= rlive ? 0xff00u : 0u;
+            } else {
+                // the row the run starts in and the one it may wrap to
+                const int ohw = oh0 + 1 < (unsigned)OH ? (int)oh0 + 1 : 0;
+                const int nw = oh0 + 1 < (unsigned)OH ? (int)n0 : min((int)n0 + 1, nimg - 1);
+                const int iy0 = (int)oh0 * 2 - 1 + ty, iy1 = ohw * 2 - 1 + ty;
+                const float* row0 = x + ((size_t)n0 * H + min(max(iy0, 0), H - 1)) * W;
+                const float* row1 = x + ((size_t)nw * H + min(max(iy1, 0), H - 1)) * W;
+                const bool ok0 = iy0 >= 0 && iy0 < H, ok1 = iy1 >= 0 && iy1 < H;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned m = m0 + j;
+                    const bool live = rlive && m < M;
+                    const bool wrap = (int)ow0 + j >= OW;
+                    const int ix = ((int)ow0 + j - (wrap ? OW : 0)) * 2 - 1 + tx;
+                    xv[u][j] = (wrap ? row1 : row0)[min(max(ix, 0), W - 1)];
+                    xok[u] |= (unsigned)(live && (wrap ? ok1 : ok0) && ix >= 0 && ix < W) << j;
+                    xok[u] |= (unsigned)live << (8 + j);
+                    d[u][j] = *reinterpret_cast<const unsigned*>(dz + (size_t)(m < M ? m : M - 1) * 64 + 2 * r);
+                }
             }
-            lv[u] = live;
         }
         // the loaded values pass through an opaque statement before they are masked, so that the
         // compiler cannot move a load under its mask's branch (which would serialise the loads)
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(WG_NT) void dconv1_bwd_weight_mfma_kernel(const flo
         for (int u = 0; u < U; ++u) {
             float av[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) av[j] = !lv[u] ? 0.f : (r < 16 ? xv[u][j] : (r == 16 ? 1.f : 0.f));
+            for (int j = 0; j < 8; ++j) av[j] = !(xok[u] >> (8 + j) & 1u) ? 0.f : (r < 16 ? xv[u][j] : (r == 16 ? 1.f : 0.f));
             const bf16x8 fa = to_bf16x8(av);
             unsigned lo[4], hi[4];
 #pragma unroll
@@ -405,8 +435,25 @@ __global__ __launch_bounds__(WG_NT) void dconv1_bwd_weight_mfma_kernel(const flo
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < WG_NT / 64; ++k) s += sm[k][row][ch];
-        unsafeAtomicAdd(row < 16 ? dw + ch * 16 + row : db + ch, s);
+        if (slab) slab[(size_t)blockIdx.x * (17 * 64) + i] = s;
+        else unsafeAtomicAdd(row < 16 ? dw + ch * 16 + row : db + ch, s);
     }
+}
+// dw / db = the slab rows added in order
+__global__ __launch_bounds__(64) void dconv1_wfold_kernel(const float* __restrict__ slab, int rows, float* __restrict__ dw,
+                                                          float* __restrict__ db) {
+    const int i = blockIdx.x * 64 + threadIdx.x;      // 17 blocks: i = row * 64 + ch
+    const int row = i >> 6, ch = i & 63;
+    float s = 0.f;
+    for (int k0 = 0; k0 < rows; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = slab[(size_t)min(k0 + k, rows - 1) * (17 * 64) + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += k0 + k < rows ? v[k] : 0.f;
+    }
+    if (row < 16) dw[ch * 16 + row] = s;
+    else db[ch] = s;
 }
 
 // C[tap][pixel] = W^T[tap][channel] * dz[pixel][channel] with two 16x16x32 MFMAs (lane (col, q)
@@ -1264,28 +1311,51 @@ extern "C" int sf_dconv1_bwd_data(const void* dz, int dtype, const float* w, flo
     return SF_OK;
 }
 
-extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, float* dw, float* db, int N, int H,
-                                    int W, int K, void* stream) {
+static long long dconv1_wgrad_grid(long long M) {
+    long long g = ((M + 15) / 16 + 2 * (WG_NT / 64) - 1) / (2 * (WG_NT / 64));
+    return g > 256 ? 256 : (g < 1 ? 1 : g);
+}
+
+extern "C" size_t sf_dconv1_bwd_weight_workspace_bytes(int N, int H, int W, int K) {
+    if (N <= 0 || H < 2 || W < 2 || K != 64) return 0;
+    const int OH = (H + 2 - 4) / 2 + 1, OW = (W + 2 - 4) / 2 + 1;
+    return (size_t)dconv1_wgrad_grid((long long)N * OH * OW) * 17 * 64 * sizeof(float);
+}
+
+extern "C" int sf_dconv1_bwd_weight_ws(const float* x, const void* dz, int dtype, float* dw, float* db, float* ws,
+                                       size_t ws_bytes, int N, int H, int W, int K, void* stream) {
     SF_REQUIRE(x && dz && dw && db, "sf_dconv1_bwd_weight: null argument");
     int OH, OW;
     if (int rc = dconv1_dims("sf_dconv1_bwd_weight", dtype, N, H, W, K, &OH, &OW)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * 16 * K, s) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float) * K, s) != hipSuccess) {
-        sf_set_error("sf_dconv1_bwd_weight: memset failed");
-        return SF_ELAUNCH;
-    }
     const int epc = dtype == SF_BF16 ? 8 : 4;
     SF_REQUIRE(NT % (2 * (K / epc)) == 0, "sf_dconv1_bwd_weight: K=%d unsupported", K);
     const int rpp = NT / (2 * (K / epc));
     const long long M = (long long)N * OH * OW;
     SF_REQUIRE(M < 0x7fffffffLL, "sf_dconv1_bwd_weight: too many pixels");
-    if (dtype == SF_BF16 && K == 64 && OW % 8 == 0) {
-        long long g = (M / 16 + 2 * (WG_NT / 64) - 1) / (2 * (WG_NT / 64));
-        if (g > 256) g = 256;
-        if (g < 1) g = 1;
-        hipLaunchKernelGGL(dconv1_bwd_weight_mfma_kernel, dim3((unsigned)g), dim3(WG_NT), 0, s, x, (const bf16*)dz, dw,
-                           db, (unsigned)M, H, W, OH, OW);
+    const bool mfma = dtype == SF_BF16 && K == 64 && OW >= 8;
+    const bool slabs = mfma && ws != nullptr;
+    if (slabs) SF_REQUIRE(ws_bytes >= sf_dconv1_bwd_weight_workspace_bytes(N, H, W, K),
+                          "sf_dconv1_bwd_weight_ws: workspace of %zu bytes, %zu needed", ws_bytes,
+                          sf_dconv1_bwd_weight_workspace_bytes(N, H, W, K));
+    if (!slabs && (hipMemsetAsync(dw, 0, sizeof(float) * 16 * K, s) != hipSuccess ||
+                   hipMemsetAsync(db, 0, sizeof(float) * K, s) != hipSuccess)) {
+        sf_set_error("sf_dconv1_bwd_weight: memset failed");
+        return SF_ELAUNCH;
+    }
+    if (mfma) {
+        const long long g = dconv1_wgrad_grid(M);
+        if (OW % 8 == 0)
+            hipLaunchKernelGGL(dconv1_bwd_weight_mfma_kernel<false>, dim3((unsigned)g), dim3(WG_NT), 0, s, x, (const bf16*)dz,
+                               dw, db, slabs ? ws : nullptr, (unsigned)M, H, W, OH, OW);
+        else
+            hipLaunchKernelGGL(dconv1_bwd_weight_mfma_kernel<true>, dim3((unsigned)g), dim3(WG_NT), 0, s, x, (const bf16*)dz,
+                               dw, db, slabs ? ws : nullptr, (unsigned)M, H, W, OH, OW);
         SF_LAUNCH_CHECK("sf_dconv1_bwd_weight");
+        if (slabs) {
+            hipLaunchKernelGGL(dconv1_wfold_kernel, dim3(17), dim3(64), 0, s, ws, (int)g, dw, db);
+            SF_LAUNCH_CHECK("sf_dconv1_bwd_weight (fold)");
+        }
         return SF_OK;
     }
     const int step = rpp * 4;
@@ -1296,6 +1366,11 @@ extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, f
                                          (const T*)dz, dw, db, (unsigned)M, (unsigned)per, H, W, K, OH, OW));
     SF_LAUNCH_CHECK("sf_dconv1_bwd_weight");
     return SF_OK;
+}
+
+extern "C" int sf_dconv1_bwd_weight(const float* x, const void* dz, int dtype, float* dw, float* db, int N, int H,
+                                    int W, int K, void* stream) {
+    return sf_dconv1_bwd_weight_ws(x, dz, dtype, dw, db, nullptr, 0, N, H, W, K, stream);
 }
 
 static int k1_dims(const char* who, int dtype, int N, int H, int W, int C, int Creal, int R, int pad, int* OH,

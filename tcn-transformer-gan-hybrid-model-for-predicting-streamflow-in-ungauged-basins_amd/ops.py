@@ -64,6 +64,7 @@ def lib():
         L.sf_enc1_bwd_workspace_bytes.restype = ctypes.c_size_t
         L.sf_enc1_codes_bytes.restype = ctypes.c_size_t
         L.sf_enc1_gram_workspace_bytes.restype = ctypes.c_size_t
+        L.sf_dconv1_bwd_weight_workspace_bytes.restype = ctypes.c_size_t
         L.sf_date_image_metrics_workspace_bytes.restype = ctypes.c_size_t
         L.sf_gru_save_floats.restype = ctypes.c_size_t
         L.sf_attn_save_floats.restype = ctypes.c_size_t
@@ -74,7 +75,7 @@ def lib():
 EXPORTS = ["sf_version", "sf_last_error", "sf_gemm", "sf_gemm_batch", "sf_conv3x3", "sf_conv3x3_dot", "sf_conv3x3_dot_ok", "sf_conv3x3_tile_shape", "sf_conv3x3_staged_weight_bytes", "sf_conv3x3_stage_weights", "sf_conv4x4s2", "sf_conv4x4s2_staged_weight_bytes", "sf_conv4x4s2_stage_weights", "sf_wgrad3x3", "sf_set_wgrad_scheduling", "sf_wgrad3x3_workspace_bytes", "sf_wgrad4x4s2", "sf_wgrad4x4s2_workspace_bytes", "sf_nchw_to_nhwc", "sf_nchw_to_nhwc_checked", "sf_nchw_bf16_to_nhwc", "sf_nhwc_to_nchw", "sf_pack_conv_weight",
            "sf_cast", "sf_bn_stats", "sf_bn_finalize", "sf_bn_relu_maxpool_fwd", "sf_bn_relu_avgpool_fwd",
            "sf_bn_lrelu_fwd", "sf_bn_bwd_reduce", "sf_bn_bwd_apply", "sf_bn_relu_avgpool_fwd_moments", "sf_bn_bwd_reduce_pooled", "sf_channel_sum", "sf_colsum_f32",
-           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_codes_bytes", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_gram", "sf_enc1_gram_workspace_bytes", "sf_enc1_stats_gram", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight",
+           "sf_bilinear_fwd", "sf_bilinear_bwd", "sf_upconv3_fwd", "sf_upconv3_bwd", "sf_enc1_stats", "sf_enc1_codes_bytes", "sf_enc1_fwd", "sf_enc1_bwd", "sf_enc1_gram", "sf_enc1_gram_workspace_bytes", "sf_enc1_stats_gram", "sf_enc1_bwd_workspace_bytes", "sf_dconv1_fwd", "sf_dconv1_bwd_data", "sf_dconv1_bwd_weight", "sf_dconv1_bwd_weight_ws", "sf_dconv1_bwd_weight_workspace_bytes",
            "sf_conv_k1_fwd", "sf_conv_k1_fwd_ws", "sf_conv_k1_fwd_workspace_bytes", "sf_conv_k1_bwd_data", "sf_conv_k1_bwd_weight", "sf_conv_k1_bwd_fused", "sf_transformer_save_floats",
            "sf_transformer_save_offset", "sf_transformer_layer_fwd", "sf_transformer_layer_bwd", "sf_add_pe", "sf_mean_t_fwd", "sf_mean_t_bwd",
            "sf_lstm_save_floats", "sf_lstm_fwd", "sf_lstm_bwd", "sf_lonlat_to_pixel", "sf_image_station_loss", "sf_image_station_loss_fwd", "sf_image_station_loss_bwd", "sf_image_station_loss_static",
@@ -869,8 +870,10 @@ def dconv1_bwd_weight(x, dz):
     K = dz.shape[-1]
     dw = torch.empty((K, 1, 4, 4), device=x.device, dtype=torch.float32)
     db = torch.empty(K, device=x.device, dtype=torch.float32)
-    _check(lib().sf_dconv1_bwd_weight(_p(x), _p(dz), code_of(dz.dtype), _p(dw), _p(db), N, H, W, K, _stream()),
-           "sf_dconv1_bwd_weight")
+    nbytes = int(lib().sf_dconv1_bwd_weight_workspace_bytes(N, H, W, K))
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    _check(lib().sf_dconv1_bwd_weight_ws(_p(x), _p(dz), code_of(dz.dtype), _p(dw), _p(db), _p(ws) if nbytes else None,
+                                         ctypes.c_size_t(nbytes), N, H, W, K, _stream()), "sf_dconv1_bwd_weight_ws")
     return dw, db
 
 

@@ -556,7 +556,9 @@ def test_dconv1_kernels_against_f32_conv(sf):
     ops = sf.ops
     torch.manual_seed(5)
     F = torch.nn.functional
-    for (N, H, W) in [(2, 64, 64), (3, 50, 50), (1, 33, 47), (2, 400, 400), (1, 2, 16),
+    for (N, H, W) in [(2, 64, 64), (3, 50, 50), (1, 33, 47), (2, 400, 400), (1, 2, 16), (2, 20, 18), (1, 2, 14),
+                      (3, 11, 23),                   # pixel runs that cross output rows and images, a partial last run
+                      (32, 200, 200),                # the benchmark's real-target branch (output width 100)
                       (32, 400, 400)]:               # the benchmark's full shape
         K = 64
         x = torch.randn(N, 1, H, W, device=DEV).to(torch.bfloat16).float()
@@ -573,6 +575,12 @@ def test_dconv1_kernels_against_f32_conv(sf):
         dw, db = ops.dconv1_bwd_weight(x, dz)
         close(dw, torch.nn.grad.conv2d_weight(x.double().cpu(), (K, 1, 4, 4), dzc, stride=2, padding=1).numpy(), 1e-4)
         close(db, dzc.sum(dim=(0, 2, 3)).numpy(), 1e-4)
+        # the entry point without a workspace (atomics into zeroed outputs) gives the same sums
+        dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+        assert ops.lib().sf_dconv1_bwd_weight(ops._p(x), ops._p(dz), ops.code_of(dz.dtype), ops._p(dw2), ops._p(db2),
+                                              N, H, W, K, ops._stream()) == 0
+        close(dw2, dw.cpu().numpy(), 1e-5)
+        close(db2, db.cpu().numpy(), 1e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
