@@ -712,25 +712,39 @@ __global__ __launch_bounds__(E_NT, 2) void enc1_bwd2_kernel(E1Bwd2 a) {
     }
 }
 
-// Sum of the workgroups' partial Gram matrices and of the input-sum slabs, in slab order
+// Sum of the workgroups' partial Gram matrices and of the input-sum slabs, in a fixed order
 // (reproducible), in double.  out: [n Gram entries][144 input sums] = the "Gram record" that the
 // statistics and the gradient finalize kernels read (SF_ENC1_GRAM_DOUBLES doubles at most).
+// A workgroup folds 32 entries: eight threads per entry take an eighth of the slabs each (one
+// thread per entry walked several hundred slabs with eight loads in flight: 58 us of latency
+// for 13 MB), and the eight partial sums are added in order.
 __global__ __launch_bounds__(256) void enc1_gram_fold_kernel(const float* __restrict__ gslab, int nslabs, int n,
                                                              const float* __restrict__ insums, double* __restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n + 144) return;
-    const float* src = e < n ? gslab + e : insums + (e - n);
-    const int cnt = e < n ? nslabs : E_SUMS_GRID;
-    const size_t stride = e < n ? (size_t)n : 144;
+    __shared__ double part[8][32];
+    const int el = threadIdx.x & 31, pt = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const bool live = e < n + 144;
+    const int ee = live ? e : 0;
+    const float* src = ee < n ? gslab + ee : insums + (ee - n);
+    const int cnt = ee < n ? nslabs : E_SUMS_GRID;
+    const size_t stride = ee < n ? (size_t)n : 144;
+    const int per = (cnt + 7) / 8, lo = pt * per, hi = lo + per < cnt ? lo + per : cnt;
     double acc = 0.0;
-    for (int i0 = 0; i0 < cnt; i0 += 8) {
+    for (int i0 = lo; i0 < hi; i0 += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(i0 + u < cnt ? i0 + u : i0) * stride];
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(i0 + u < hi ? i0 + u : i0) * stride];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += i0 + u < cnt ? (double)v[u] : 0.0;
+        for (int u = 0; u < 8; ++u) acc += i0 + u < hi ? (double)v[u] : 0.0;
     }
-    out[e] = acc;
+    part[pt][el] = acc;
+    __syncthreads();
+    if (pt == 0 && live) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][el];
+        out[e] = t;
+    }
 }
 
 // S[(tap, c)] = sum over the output pixels of the input value under tap (ty, tx): every pixel of
@@ -1088,7 +1102,7 @@ static int gram_record(const E1Params& c, int Creal, bool accumulate_here, float
         if (int rc = launch_bwd2<2>(a, nct, gx, 1, s, who)) return rc;
     }
     hipLaunchKernelGGL(enc1_input_sums_kernel, dim3(E_SUMS_GRID), dim3(E_NT), 0, s, c.x, insums, c.N, c.H, c.W);
-    hipLaunchKernelGGL(enc1_gram_fold_kernel, dim3((np * 1024 + 144 + 255) / 256), dim3(256), 0, s, gslab, gx, np * 1024, insums, rec);
+    hipLaunchKernelGGL(enc1_gram_fold_kernel, dim3((np * 1024 + 144 + 31) / 32), dim3(256), 0, s, gslab, gx, np * 1024, insums, rec);
     return SF_OK;
 }
 
