@@ -171,6 +171,40 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict_
     }
 }
 
+// Many channels: the mirror of nchw_to_nhwc_tile_kernel.  A workgroup moves 64 pixels x 64 channels
+// through LDS: pixel rows are read in 256-byte (f32) / 128-byte (bf16) runs, channel planes written
+// in 256-byte runs (read directly, a wave touches 64 lines per load).
+template <typename T>
+__global__ __launch_bounds__(NT) void nhwc_to_nchw_tile_kernel(const T* __restrict__ in, float* __restrict__ out, int C,
+                                                               int HW, int Cpad, int ptiles, int ctiles) {
+    __shared__ float sm[64][65];                 // [pixel][channel]
+    const int ct = blockIdx.x % ctiles, rest = blockIdx.x / ctiles;
+    const int pt = rest % ptiles, n = rest / ptiles;
+    const int c0 = ct * 64, p0 = pt * 64;
+    {
+        const int ch = threadIdx.x & 63, pq = threadIdx.x >> 6;
+        const bool cok = c0 + ch < C;
+        const T* src = in + ((size_t)n * HW + p0) * Cpad + c0 + (cok ? ch : 0);
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int px = pq * 16 + i;
+            v[i] = to_f32(src[(size_t)(p0 + px < HW ? px : 0) * Cpad]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sm[pq * 16 + i][ch] = v[i];
+    }
+    __syncthreads();
+    const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    if (p0 + px < HW) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = cq * 16 + i;
+            if (c0 + ch < C) out[((size_t)n * C + c0 + ch) * HW + p0 + px] = sm[px][ch];
+        }
+    }
+}
+
 struct PackArgs {
     int O, I, RS, transpose, ntaps, rows_pad, cols_pad;
     int tap_rs[16];
@@ -564,6 +598,16 @@ extern "C" int sf_nhwc_to_nchw(const void* in, int dtype, float* out, int N, int
                                void* stream) {
     SF_REQUIRE(in && out && N > 0 && C > 0 && Cpad >= C, "sf_nhwc_to_nchw: bad arguments");
     const long long total = (long long)N * C * H * W;
+    if (C >= 32 && NT == 256) {
+        const int HWi = H * W, ptiles = (HWi + 63) / 64, ctiles = (C + 63) / 64;
+        const long long blocks = (long long)N * ptiles * ctiles;
+        if (blocks < 0x7fffffffLL) {
+            DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_tile_kernel<T>, dim3((unsigned)blocks), dim3(NT), 0,
+                                                 (hipStream_t)stream, (const T*)in, out, C, HWi, Cpad, ptiles, ctiles));
+            SF_LAUNCH_CHECK("sf_nhwc_to_nchw");
+            return SF_OK;
+        }
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for(total)), dim3(NT), 0,
                                          (hipStream_t)stream, (const T*)in, out, total, C, H * W, Cpad));
     SF_LAUNCH_CHECK("sf_nhwc_to_nchw");

@@ -583,6 +583,35 @@ def test_dconv1_kernels_against_f32_conv(sf):
         close(db2, db.cpu().numpy(), 1e-5)
 
 
+def test_layout_passes_against_torch(sf):
+    """The NCHW <-> NHWC layout passes only move (and round) values: exact against torch.  Few-channel
+    form (4 pixels per thread, pieces regrouped through LDS) with and without the Inf/NaN flag of
+    src/train.py:193, partial last quads; many-channel tiled transposes in both directions with
+    partial pixel and channel tiles, f32 and bf16 sources."""
+    ops = sf.ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for (N, C, H, W, cpad, with_flag) in [(160, 10, 200, 200, 16, True), (3, 10, 6, 6, 16, False), (1, 3, 2, 2, 8, True),
+                                          (5, 7, 10, 6, 8, False), (2, 13, 17, 4, 16, True), (7, 1, 3, 4, 8, False),
+                                          (2, 70, 9, 7, 72, False)]:
+        x = torch.randn((N, C, H, W), device=DEV, generator=g)
+        flag = torch.zeros(1, device=DEV, dtype=torch.int32) if with_flag else None
+        y = ops.nchw_to_nhwc(x, torch.bfloat16, cpad, flag)
+        ref = torch.zeros((N, H, W, cpad), device=DEV, dtype=torch.bfloat16)
+        ref[..., :C] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+        assert torch.equal(y, ref), (N, C, H, W, cpad)
+        if with_flag:
+            assert int(flag.item()) == 0
+            x[N - 1, C - 1, H - 1, W - 1] = float("nan")
+            ops.nchw_to_nhwc(x, torch.bfloat16, cpad, flag)
+            assert int(flag.item()) == 1
+    for (N, C, H, W, cpad, dt) in [(32, 256, 32, 32, 256, torch.float32), (2, 70, 9, 7, 72, torch.float32),
+                                   (3, 33, 5, 13, 40, torch.bfloat16), (1, 32, 1, 1, 32, torch.float32),
+                                   (2, 10, 6, 6, 16, torch.bfloat16), (1, 64, 8, 8, 64, torch.bfloat16)]:
+        xh = torch.randn((N, H, W, cpad), device=DEV, generator=g).to(dt)
+        out = ops.nhwc_to_nchw(xh, C)
+        assert torch.equal(out, xh[..., :C].float().permute(0, 3, 1, 2).contiguous()), (N, C, H, W, cpad, dt)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upconv3_against_interpolate_then_conv(sf, dtype):
     """sf_upconv3_fwd / sf_upconv3_bwd (3x3 conv of a bilinearly resized map, resized map never
