@@ -1,39 +1,38 @@
-"""The two 262144-wide Linear layers at the benchmark shape: time of forward and backward, and the
-bytes each must move."""
-import importlib, os, sys
+"""Times the two 262144-wide Linear layers (forward, input gradient, weight gradient) in bf16."""
+import importlib
+import os
+import sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-pkg = importlib.import_module("tcn-transformer-gan-hybrid-model-for-predicting-streamflow-in-ungauged-basins_amd")
-SF = importlib.import_module(pkg.__name__ + ".functional")
-ops = pkg.ops
-torch.manual_seed(0)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sf = importlib.import_module("tcn-transformer-gan-hybrid-model-for-predicting-streamflow-in-ungauged-basins_amd")
+SF = sf.functional if hasattr(sf, "functional") else importlib.import_module(sf.__name__ + ".functional")
 
 
-def timed(name, fn, nbytes, n=10):
+def timed(fn, n=20):
     for _ in range(3):
         fn()
-    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(n):
         fn()
-    e.record()
+    e1.record()
     torch.cuda.synchronize()
-    us = 1e3 * a.elapsed_time(e) / n
-    print(f"{name}: {us:.1f} us, {nbytes / us / 1e6:.2f} TB/s of {nbytes / 1e6:.0f} MB", flush=True)
+    return e0.elapsed_time(e1) / n * 1e3
 
 
-for (M, K, N) in ((160, 262144, 128), (32, 128, 262144)):
-    lin = torch.nn.Linear(K, N).cuda()
-    sh = lin.weight.detach().to(torch.bfloat16)
-    x = torch.randn(M, K, device="cuda", requires_grad=True)
-    dy = torch.randn(M, N, device="cuda")
-    y = SF.LinearFn.apply(x, lin.weight, lin.bias, torch.bfloat16, sh)
-    fwd_bytes = M * K * 4 + M * K * 2 + N * K * 2 + M * N * 4          # x f32 read + bf16 write/read folded, W bf16, y
-    timed(f"fwd  M={M} K={K} N={N}", lambda: SF.LinearFn.apply(x, lin.weight, lin.bias, torch.bfloat16, sh), fwd_bytes)
+for (M, K, Nf, xdt) in [(160, 262144, 128, torch.bfloat16), (32, 128, 262144, torch.float32)]:
+    x = torch.randn(M, K, device="cuda").to(xdt).requires_grad_(True)
+    W = (torch.randn(Nf, K, device="cuda") * 0.01).requires_grad_(True)
+    b = torch.zeros(Nf, device="cuda", requires_grad=True)
+    sh = W.detach().to(torch.bfloat16)
+    y = SF.LinearFn.apply(x, W, b, torch.bfloat16, sh)
+    dy = torch.randn_like(y)
+    fwd = timed(lambda: SF.LinearFn.apply(x, W, b, torch.bfloat16, sh))
 
-    def bwd():
-        yy = SF.LinearFn.apply(x, lin.weight, lin.bias, torch.bfloat16, sh)
-        yy.backward(dy)
-        x.grad = None; lin.weight.grad = None; lin.bias.grad = None
-    bwd_bytes = fwd_bytes + N * K * 2 + M * K * 4 + M * K * 2 + N * K * 4
-    timed(f"fwd+bwd", bwd, bwd_bytes)
+    def both():
+        x.grad = W.grad = b.grad = None
+        SF.LinearFn.apply(x, W, b, torch.bfloat16, sh).backward(dy)
+    tot = timed(both)
+    print(f"Linear {K}->{Nf}, {M} rows: forward {fwd:.1f} us, forward + backward {tot:.1f} us (SF_GEMM_PF2={os.environ.get('SF_GEMM_PF2', '1')})")
