@@ -67,6 +67,7 @@ struct KParams {
     const void* aux;
     long long I, J, R, lda, ldb, ldo;
     int niters, iters_per_split, nsplit, nsplit_req, ni_tiles, nj_tiles;
+    int j_fast;   // consecutive workgroups walk the j tiles of one i tile (they share its A tile in L2) instead of the i tiles of one j tile
     int b_gather, out_mode, out_dtype, act, aux_mode, atomic;
     long long split_stride;   // > 0: split s stores its partial result at out + s * split_stride (no atomics)
     unsigned long long dy_pack, dx_pack;  // tap offsets + 8, 4 bits per tap
@@ -120,10 +121,19 @@ __device__ __forceinline__ void gemm_body(const KParams& p, const int block_id, 
 
     // block -> (i tile, j tile, split)
     int lin = xcd_remap(block_id, nwg);
-    const int it_i = lin % p.ni_tiles;
-    lin /= p.ni_tiles;
-    const int it_j = lin % p.nj_tiles;
-    const int split = lin / p.nj_tiles;
+    int it_i, it_j;
+    if (p.j_fast) {
+        it_j = lin % p.nj_tiles;
+        lin /= p.nj_tiles;
+        it_i = lin % p.ni_tiles;
+        lin /= p.ni_tiles;
+    } else {
+        it_i = lin % p.ni_tiles;
+        lin /= p.ni_tiles;
+        it_j = lin % p.nj_tiles;
+        lin /= p.nj_tiles;
+    }
+    const int split = lin;
     const long long i0 = (long long)it_i * TI, j0 = (long long)it_j * TJ;
     const int iter_begin = split * p.iters_per_split;
     int iter_end = iter_begin + p.iters_per_split;
@@ -442,6 +452,9 @@ int launch_one(const KParams& q, hipStream_t s) {
     p.nsplit = ceil_div(p.niters, p.iters_per_split);
     p.ni_tiles = ceil_div(p.I, TI);
     p.nj_tiles = ceil_div(p.J, TJ);
+    // the operand with the many tiles is the one worth sharing: a 262144 x 128 weight against 160 rows
+    // has 2048 i tiles and two j tiles, and i-fastest order read every weight tile from HBM twice
+    p.j_fast = p.nj_tiles < p.ni_tiles ? 1 : 0;
     const long long nblk = (long long)p.ni_tiles * p.nj_tiles * p.nsplit;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         sf_set_error("sf_gemm: bad grid (%lld blocks)", nblk);
@@ -527,6 +540,7 @@ static int fill_kparams(const sf_gemm_desc* d, const void* A, const void* B, con
     p.niters = p.iters_per_split = p.nsplit = 0;   // set per kernel variant in launch_one
     p.nsplit_req = d->nsplit;
     p.ni_tiles = p.nj_tiles = 0;
+    p.j_fast = 0;
     p.b_gather = d->b_gather; p.out_mode = d->out_mode; p.out_dtype = d->out_dtype;
     p.act = d->act; p.aux_mode = d->aux_mode; p.g = d->g;
     p.dy_pack = p.dx_pack = 0;

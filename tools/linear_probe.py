@@ -36,3 +36,22 @@ for (M, K, Nf, xdt) in [(160, 262144, 128, torch.bfloat16), (32, 128, 262144, to
         SF.LinearFn.apply(x, W, b, torch.bfloat16, sh).backward(dy)
     tot = timed(both)
     print(f"Linear {K}->{Nf}, {M} rows: forward {fwd:.1f} us, forward + backward {tot:.1f} us (SF_GEMM_PF2={os.environ.get('SF_GEMM_PF2', '1')})")
+
+# the pieces of the backward, one by one
+ops = sf.ops
+for (M, K, Nf, xdt) in [(160, 262144, 128, torch.bfloat16), (32, 128, 262144, torch.float32)]:
+    xt = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    Wt = (torch.randn(Nf, K, device="cuda") * 0.01).to(torch.bfloat16)
+    dy = torch.randn(M, Nf, device="cuda")
+    bk = 32
+    t_cast = timed(lambda: ops.cast(dy, torch.bfloat16))
+    dyt = ops.cast(dy, torch.bfloat16)
+    nsplit = max(1, min(256, Nf // (bk * 16)))
+    t_dx = timed(lambda: SF._split_gemm(Wt, dyt, K, M, Nf, K, Nf, K, True, nsplit, None,
+                                        out_dtype=torch.bfloat16 if xdt == torch.bfloat16 else torch.float32))
+    dW = torch.empty((Nf, K), device="cuda", dtype=torch.float32)
+    t_dw = timed(lambda: ops.linear_gemm(dyt, xt, dW, Nf, K, M, Nf, K, K, True, True, ops.OUT_IJ, 1))
+    t_db = timed(lambda: ops.colsum_f32(dy))
+    nsf = max(1, min(256, K // (bk * 16)))
+    t_fw = timed(lambda: SF._split_gemm(Wt, xt, Nf, M, K, K, K, Nf, False, nsf, None))
+    print(f"Linear {K}->{Nf}, {M} rows: cast dy {t_cast:.1f}, dx {t_dx:.1f} (nsplit {nsplit}), dW {t_dw:.1f}, db {t_db:.1f}, forward gemm {t_fw:.1f} (nsplit {nsf}) us")
