@@ -1,5 +1,5 @@
 #!/bin/bash
-# First GPU session of round 3: GPU tests, default bench, counter passes, kernel trace.
+# GPU tests, default bench, counter passes, kernel trace.
 # Every GPU step has its own time limit; the chain stops at the first failure.
 export TMPDIR=/tmp
 mkdir -p gpurun_out
