@@ -581,6 +581,14 @@ def test_dconv1_kernels_against_f32_conv(sf):
                                               N, H, W, K, ops._stream()) == 0
         close(dw2, dw.cpu().numpy(), 1e-5)
         close(db2, db.cpu().numpy(), 1e-5)
+    # a workspace smaller than sf_dconv1_bwd_weight_workspace_bytes is refused before anything is launched
+    import ctypes
+    need = int(ops.lib().sf_dconv1_bwd_weight_workspace_bytes(N, H, W, K))
+    assert need > 0
+    small = torch.empty(max(need // 4 - 1, 1), device=DEV, dtype=torch.float32)
+    rc = ops.lib().sf_dconv1_bwd_weight_ws(ops._p(x), ops._p(dz), ops.code_of(dz.dtype), ops._p(dw2), ops._p(db2), ops._p(small),
+                                           ctypes.c_size_t(need - 4), N, H, W, K, ops._stream())
+    assert rc != 0 and b"workspace" in ops.lib().sf_last_error()
 
 
 def test_layout_passes_against_torch(sf):
